@@ -1,0 +1,345 @@
+// Tile binning: which 16x16 screen tiles does each projected Gaussian touch, and in what
+// depth order does each tile see them.  Replaces gsplat.isect_tiles (two-pass count/emit +
+// a device-wide 64-bit radix sort) and isect_offset_encode (IDX:14360, IDX:14369).
+//
+// MI355X design: instead of one global radix sort over (tile|depth) keys -- 6 passes x 24 B
+// per intersection through HBM -- intersections are bucketed by tile with one counting pass
+// (per-tile histogram -> exclusive scan -> scatter) and every tile's list is then sorted on
+// (depth bits, Gaussian index) by one workgroup entirely inside LDS (160 KiB per CU).  The
+// composite key makes the result independent of scatter order and identical to a stable
+// global sort of the gsplat key.  Wave64 lanes that hit the same tile are merged with a
+// ballot so hot tiles see one atomic per wave instead of 64.
+#include "gsloc_common.h"
+
+namespace gsl {
+
+#define GSL_SORT_LDS_CAP 8192  // intersections per tile sorted in LDS (64 KiB); longer lists sort in global memory
+
+// Per-wave merged atomic add of 1 on ctr[key]: lanes holding the same key elect a leader.
+// Returns the position (old value + rank among equal lanes) for `active` lanes.
+// At most MERGE_ROUNDS leader rounds, the rest fall back to plain atomics (random screen order).
+__device__ __forceinline__ int merged_atomic_inc(int32_t* __restrict__ ctr, int key, bool active) {
+  int pos = 0;
+  unsigned long long todo = __ballot(active);
+  int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int round = 0; round < 4 && todo; ++round) {
+    int leader = __ffsll((long long)todo) - 1;
+    int lkey = __shfl(key, leader, 64);
+    unsigned long long same = __ballot(active && key == lkey) & todo;
+    int cnt = __popcll(same);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&ctr[lkey], cnt);
+    base = __shfl(base, leader, 64);
+    if ((same >> lane) & 1ull) {
+      pos = base + __popcll(same & ((1ull << lane) - 1ull));
+      active = false;
+    }
+    todo &= ~same;
+  }
+  if (active) pos = atomicAdd(&ctr[key], 1);
+  return pos;
+}
+
+// Pass 1: per-Gaussian tile count (strip-clipped) + per-tile histogram.
+__global__ __launch_bounds__(256) void k_isect_count(const float* __restrict__ means2d,
+                                                     const int32_t* __restrict__ radii, int N, int tile_size,
+                                                     int tile_w, int tile_h, int ty0, int ty1,
+                                                     int32_t* __restrict__ tiles_per_gauss,
+                                                     int32_t* __restrict__ tile_counts) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+  if (i < N) {
+    int r = radii[i];
+    if (r > 0) {
+      tile_rect(means2d[2 * (size_t)i], means2d[2 * (size_t)i + 1], r, tile_size, tile_w, tile_h, xmin, ymin, xmax,
+                ymax);
+      ymin = max(ymin, ty0);
+      ymax = min(ymax, ty1);
+      if (ymax < ymin) ymax = ymin;
+    }
+    if (tiles_per_gauss) tiles_per_gauss[i] = (xmax - xmin) * (ymax - ymin);
+  }
+  // walk the rectangle; all lanes of the wave iterate together so the ballot merge sees them
+  int w = xmax - xmin, n = w * (ymax - ymin);
+  int nmax = n;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  for (int k = 0; k < nmax; ++k) {
+    bool act = k < n;
+    int t = 0;
+    if (act) t = (ymin + k / w) * tile_w + xmin + k % w;
+    merged_atomic_inc(tile_counts, t, act);
+  }
+}
+
+// Exclusive scan of tile_counts[n] -> offsets[n+1]; total -> n_isects; zero the cursors.
+__global__ __launch_bounds__(1024) void k_tile_scan(const int32_t* __restrict__ counts, int n,
+                                                    int32_t* __restrict__ offsets, int32_t* __restrict__ n_isects,
+                                                    int32_t* __restrict__ cursors) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + tid;
+    int v = (i < n) ? counts[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    int carry = carry_s;
+    if (i < n) {
+      offsets[i] = carry + woff + x - v;
+      cursors[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    offsets[n] = carry_s;
+    n_isects[0] = carry_s;
+  }
+}
+
+// Pass 2: scatter (depth bits, Gaussian id) into the tile buckets.
+__global__ __launch_bounds__(256) void k_isect_scatter(const float* __restrict__ means2d,
+                                                       const int32_t* __restrict__ radii,
+                                                       const float* __restrict__ depths, int N, int tile_size,
+                                                       int tile_w, int tile_h, int ty0, int ty1,
+                                                       const int32_t* __restrict__ tile_offsets,
+                                                       int32_t* __restrict__ cursors, long long capacity,
+                                                       uint64_t* __restrict__ keys) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+  uint64_t key = 0;
+  if (i < N) {
+    int r = radii[i];
+    if (r > 0) {
+      tile_rect(means2d[2 * (size_t)i], means2d[2 * (size_t)i + 1], r, tile_size, tile_w, tile_h, xmin, ymin, xmax,
+                ymax);
+      ymin = max(ymin, ty0);
+      ymax = min(ymax, ty1);
+      if (ymax < ymin) ymax = ymin;
+      key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
+    }
+  }
+  int w = xmax - xmin, n = w * (ymax - ymin);
+  int nmax = n;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  for (int k = 0; k < nmax; ++k) {
+    bool act = k < n;
+    int t = 0;
+    if (act) t = (ymin + k / w) * tile_w + xmin + k % w;
+    int p = merged_atomic_inc(cursors, t, act);
+    if (act) {
+      long long pos = (long long)tile_offsets[t] + p;
+      if (pos < capacity) keys[pos] = key;
+    }
+  }
+}
+
+// Ascending-only bitonic network on n (arbitrary) 64-bit keys; comparators whose upper index
+// falls past n are skipped (equivalent to +inf padding).  Works on LDS or global memory.
+__device__ __forceinline__ void bitonic_sort(uint64_t* a, int n, int tid, int nthreads) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  int half = P >> 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    int hk = k >> 1;
+    for (int i = tid; i < half; i += nthreads) {
+      int blk = i / hk, off = i - blk * hk;
+      int lo = blk * k + off;
+      int hi = blk * k + (k - 1 - off);
+      if (hi < n) {
+        uint64_t x = a[lo], y = a[hi];
+        if (x > y) { a[lo] = y; a[hi] = x; }
+      }
+    }
+    __syncthreads();
+    for (int j = hk >> 1; j >= 1; j >>= 1) {
+      for (int i = tid; i < half; i += nthreads) {
+        int blk = i / j, off = i - blk * j;
+        int lo = blk * 2 * j + off;
+        int hi = lo + j;
+        if (hi < n) {
+          uint64_t x = a[lo], y = a[hi];
+          if (x > y) { a[lo] = y; a[hi] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// One workgroup per tile: sort the tile's bucket, write flatten_ids (+ gsplat-style isect_ids).
+__global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ tile_offsets, int tile_begin,
+                                                   long long capacity, uint64_t* __restrict__ keys,
+                                                   int32_t* __restrict__ flatten_ids,
+                                                   int64_t* __restrict__ isect_ids, int64_t cam_enc) {
+  __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
+  int t = tile_begin + blockIdx.x;
+  long long s = tile_offsets[t], e = tile_offsets[t + 1];
+  if (e > capacity) e = capacity;
+  if (s >= e) return;
+  int n = (int)(e - s);
+  int tid = threadIdx.x;
+  uint64_t* src = keys + s;
+  if (n <= GSL_SORT_LDS_CAP) {
+    for (int i = tid; i < n; i += 256) skeys[i] = src[i];
+    __syncthreads();
+    if (n > 1) bitonic_sort(skeys, n, tid, 256);
+    for (int i = tid; i < n; i += 256) {
+      uint64_t k = skeys[i];
+      flatten_ids[s + i] = (int32_t)(uint32_t)k;
+      if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
+    }
+  } else {
+    __syncthreads();
+    bitonic_sort(src, n, tid, 256);  // rare: huge tile list, sort in place in global memory
+    for (int i = tid; i < n; i += 256) {
+      uint64_t k = src[i];
+      flatten_ids[s + i] = (int32_t)(uint32_t)k;
+      if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
+    }
+  }
+}
+
+// isect_tiles(sort=False): emit in Gaussian order at cum_tiles positions.
+__global__ __launch_bounds__(256) void k_isect_emit(const float* __restrict__ means2d,
+                                                    const int32_t* __restrict__ radii,
+                                                    const float* __restrict__ depths,
+                                                    const int64_t* __restrict__ cum_tiles, int N, int tile_size,
+                                                    int tile_w, int tile_h, int64_t cam_enc, int id_offset,
+                                                    int64_t* __restrict__ isect_ids,
+                                                    int32_t* __restrict__ flatten_ids) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int r = radii[i];
+  if (r <= 0) return;
+  int xmin, ymin, xmax, ymax;
+  tile_rect(means2d[2 * (size_t)i], means2d[2 * (size_t)i + 1], r, tile_size, tile_w, tile_h, xmin, ymin, xmax, ymax);
+  int64_t cur = (i == 0) ? 0 : cum_tiles[i - 1];
+  int64_t dbits = (int64_t)__float_as_uint(depths[i]);
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) {
+      int64_t tile = (int64_t)y * tile_w + x;
+      isect_ids[cur] = cam_enc | (tile << 32) | dbits;
+      flatten_ids[cur] = id_offset + i;
+      ++cur;
+    }
+}
+
+// isect_offset_encode: offsets[q] = first index whose (cam,tile) >= q.
+__global__ __launch_bounds__(256) void k_isect_offsets(const int64_t* __restrict__ isect_ids, long long n,
+                                                       int n_cameras, int n_tiles, int tile_n_bits,
+                                                       int32_t* __restrict__ offsets) {
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long total = (long long)n_cameras * n_tiles;
+  if (n == 0) {
+    if (idx < total) offsets[idx] = 0;
+    return;
+  }
+  if (idx >= n) return;
+  int64_t mask = ((int64_t)1 << tile_n_bits) - 1;
+  int64_t id = isect_ids[idx];
+  long long cur = (id >> (32 + tile_n_bits)) * n_tiles + ((id >> 32) & mask);
+  if (idx == 0) {
+    for (long long q = 0; q <= cur; ++q) offsets[q] = 0;
+  }
+  if (idx == n - 1) {
+    for (long long q = cur + 1; q < total; ++q) offsets[q] = (int32_t)n;
+  }
+  if (idx > 0) {
+    int64_t pid = isect_ids[idx - 1];
+    long long prev = (pid >> (32 + tile_n_bits)) * n_tiles + ((pid >> 32) & mask);
+    for (long long q = prev + 1; q <= cur; ++q) offsets[q] = (int32_t)idx;
+  }
+}
+
+}  // namespace gsl
+
+extern "C" size_t gsl_isect_ws_bytes(int n_tiles) {
+  // [tile_counts n_tiles][cursors n_tiles]
+  return (size_t)2 * (size_t)(n_tiles > 0 ? n_tiles : 1) * sizeof(int32_t);
+}
+
+extern "C" int gsl_isect_count(const float* means2d, const int32_t* radii, int N, int tile_size, int tile_w,
+                               int tile_h, int ty0, int ty1, int32_t* tiles_per_gauss, int32_t* tile_offsets,
+                               int32_t* n_isects, void* ws, size_t ws_bytes, void* stream) {
+  if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1)
+    return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !n_isects || (N > 0 && (!means2d || !radii))) return GSL_ERR_BAD_ARG;
+  int n_tiles = tile_w * tile_h;
+  if (!ws || ws_bytes < gsl_isect_ws_bytes(n_tiles)) return GSL_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* counts = (int32_t*)ws;
+  int32_t* cursors = counts + n_tiles;
+  if (hipMemsetAsync(counts, 0, (size_t)n_tiles * sizeof(int32_t), st) != hipSuccess) return GSL_ERR_HIP;
+  if (N > 0) {
+    hipLaunchKernelGGL(gsl::k_isect_count, dim3((N + 255) / 256), dim3(256), 0, st, means2d, radii, N, tile_size,
+                       tile_w, tile_h, ty0, ty1, tiles_per_gauss, counts);
+    GSL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(gsl::k_tile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_isect_fill(const float* means2d, const int32_t* radii, const float* depths, int N, int tile_size,
+                              int tile_w, int tile_h, int ty0, int ty1, int cam_id, int tile_n_bits,
+                              const int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
+                              int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes, void* stream) {
+  if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (!tile_offsets) return GSL_ERR_BAD_ARG;
+  if (N == 0 || capacity == 0 || ty0 == ty1) return GSL_OK;
+  if (!means2d || !radii || !depths || !sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
+  int n_tiles = tile_w * tile_h;
+  if (!ws || ws_bytes < gsl_isect_ws_bytes(n_tiles)) return GSL_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* cursors = (int32_t*)ws + n_tiles;
+  hipLaunchKernelGGL(gsl::k_isect_scatter, dim3((N + 255) / 256), dim3(256), 0, st, means2d, radii, depths, N,
+                     tile_size, tile_w, tile_h, ty0, ty1, tile_offsets, cursors, (long long)capacity, sort_keys);
+  GSL_CHECK_LAUNCH();
+  int64_t cam_enc = (int64_t)cam_id << (32 + tile_n_bits);
+  int strip_tiles = (ty1 - ty0) * tile_w;
+  hipLaunchKernelGGL(gsl::k_tile_sort, dim3(strip_tiles), dim3(256), 0, st, tile_offsets, ty0 * tile_w,
+                     (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_isect_emit(const float* means2d, const int32_t* radii, const float* depths,
+                              const int64_t* cum_tiles, int N, int tile_size, int tile_w, int tile_h, int cam_id,
+                              int tile_n_bits, int id_offset, int64_t* isect_ids, int32_t* flatten_ids,
+                              void* stream) {
+  if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return GSL_ERR_BAD_ARG;
+  if (N == 0) return GSL_OK;
+  if (!means2d || !radii || !depths || !cum_tiles || !isect_ids || !flatten_ids) return GSL_ERR_BAD_ARG;
+  int64_t cam_enc = (int64_t)cam_id << (32 + tile_n_bits);
+  hipLaunchKernelGGL(gsl::k_isect_emit, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, means2d, radii,
+                     depths, cum_tiles, N, tile_size, tile_w, tile_h, cam_enc, id_offset, isect_ids, flatten_ids);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_isect_offsets(const int64_t* isect_ids, int64_t n_isects, int n_cameras, int n_tiles,
+                                 int tile_n_bits, int32_t* offsets, void* stream) {
+  if (n_isects < 0 || n_cameras <= 0 || n_tiles <= 0 || !offsets) return GSL_ERR_BAD_ARG;
+  if (n_isects > 0 && !isect_ids) return GSL_ERR_BAD_ARG;
+  long long work = n_isects > 0 ? (long long)n_isects : (long long)n_cameras * n_tiles;
+  hipLaunchKernelGGL(gsl::k_isect_offsets, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     isect_ids, (long long)n_isects, n_cameras, n_tiles, tile_n_bits, offsets);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}

@@ -1,0 +1,115 @@
+// Shared device helpers for libgsloc_hip (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsloc_hip.h"
+
+#define GSL_WAVE 64
+#define GSL_ALPHA_MAX 0.999f
+#define GSL_ALPHA_MIN (1.0f / 255.0f)
+#define GSL_T_STOP 1e-4f
+
+#define GSL_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return GSL_ERR_HIP;               \
+  } while (0)
+
+namespace gsl {
+
+struct M3 {  // row-major 3x3
+  float m[9];
+  __device__ __forceinline__ float& operator()(int r, int c) { return m[r * 3 + c]; }
+  __device__ __forceinline__ float operator()(int r, int c) const { return m[r * 3 + c]; }
+};
+
+__device__ __forceinline__ M3 mul(const M3& a, const M3& b) {
+  M3 o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      o(i, j) = a(i, 0) * b(0, j) + a(i, 1) * b(1, j) + a(i, 2) * b(2, j);
+  return o;
+}
+__device__ __forceinline__ M3 mul_bt(const M3& a, const M3& b) {  // a * b^T
+  M3 o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      o(i, j) = a(i, 0) * b(j, 0) + a(i, 1) * b(j, 1) + a(i, 2) * b(j, 2);
+  return o;
+}
+__device__ __forceinline__ M3 mul_at(const M3& a, const M3& b) {  // a^T * b
+  M3 o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      o(i, j) = a(0, i) * b(0, j) + a(1, i) * b(1, j) + a(2, i) * b(2, j);
+  return o;
+}
+
+// wxyz quaternion (normalised here) -> rotation matrix.
+__device__ __forceinline__ M3 quat_to_rotmat(float w, float x, float y, float z) {
+  float inv = rsqrtf(w * w + x * x + y * y + z * z);
+  w *= inv; x *= inv; y *= inv; z *= inv;
+  M3 R;
+  R(0, 0) = 1.f - 2.f * (y * y + z * z); R(0, 1) = 2.f * (x * y - w * z); R(0, 2) = 2.f * (x * z + w * y);
+  R(1, 0) = 2.f * (x * y + w * z); R(1, 1) = 1.f - 2.f * (x * x + z * z); R(1, 2) = 2.f * (y * z - w * x);
+  R(2, 0) = 2.f * (x * z - w * y); R(2, 1) = 2.f * (y * z + w * x); R(2, 2) = 1.f - 2.f * (x * x + y * y);
+  return R;
+}
+
+// Sigma = (Rq S)(Rq S)^T
+__device__ __forceinline__ M3 quat_scale_to_covar(const float q[4], const float s[3]) {
+  M3 R = quat_to_rotmat(q[0], q[1], q[2], q[3]);
+  M3 M;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M(i, j) = R(i, j) * s[j];
+  return mul_bt(M, M);
+}
+
+struct Cam {  // wave-uniform camera constants (scalar registers)
+  M3 R;
+  float t[3];
+  float fx, fy, cx, cy;
+};
+
+__device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float* __restrict__ K) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) c.R(i, j) = V[i * 4 + j];
+    c.t[i] = V[i * 4 + 3];
+  }
+  c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+  return c;
+}
+
+// 64-lane butterfly sum (DPP/ds_swizzle under the hood); every lane gets the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Tile rectangle of a projected Gaussian: [xmin,xmax) x [ymin,ymax) in tiles.
+__device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tile_size, int tile_w,
+                                          int tile_h, int& xmin, int& ymin, int& xmax, int& ymax) {
+  float ts = (float)tile_size;
+  float tr = (float)radius / ts;
+  float tx = mx / ts, ty = my / ts;
+  // clamp in float first: (uint32_t)floor(negative) saturates to 0 in the reference kernel
+  xmin = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tile_w);
+  ymin = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)tile_h);
+  xmax = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tile_w);
+  ymax = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)tile_h);
+}
+
+}  // namespace gsl

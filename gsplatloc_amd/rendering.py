@@ -1,0 +1,179 @@
+"""``rasterization`` -- the one gsplat entry point GsplatLoc calls.
+
+Call sites replaced: /root/reference/src/my_gsplat/model.py:195-213 (grad,
+"RGB+ED") and /root/reference/src/my_gsplat/geometry.py:117-132 (no_grad,
+"ED").  Signature, defaults, return triple and meta keys follow
+``gsplat.rendering.rasterization`` of gsplat 1.3.0 (IDX:14954); the stages run
+on the HIP kernels of libgsloc_hip (see ``ops.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+from typing_extensions import Literal
+
+from .ops import (
+    fully_fused_projection,
+    isect_offset_encode,
+    isect_tiles,
+    rasterize_to_pixels,
+    spherical_harmonics,
+)
+
+
+def rasterization(
+    means: Tensor,  # [N, 3]
+    quats: Tensor,  # [N, 4]
+    scales: Tensor,  # [N, 3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [(C,) N, D] or [(C,) N, K, 3]
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: Literal["RGB", "D", "ED", "RGB+D", "RGB+ED"] = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: Literal["classic", "antialiased"] = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    ortho: bool = False,
+    covars: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterize a set of 3D Gaussians to a batch of C image planes.
+
+    Returns (render_colors [C,H,W,X], render_alphas [C,H,W,1], meta).  X is D for
+    "RGB", 1 for "D"/"ED", D+1 for "RGB+D"/"RGB+ED"; "ED" divides the accumulated
+    depth by alpha ("expected depth").
+
+    ``packed`` only changes gsplat's internal memory layout, never the rendered
+    result; this implementation always computes densely and returns the dense
+    ([C,N,...]) meta tensors.
+    """
+    meta: Dict = {}
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    if covars is not None:
+        raise NotImplementedError("covars input is not supported; pass quats and scales")
+    if distributed:
+        raise NotImplementedError("gsplat's Gaussian-sharded distributed mode is not part of GsplatLoc's path; "
+                                  "use gsplatloc_amd.parallel for screen-tile parallelism")
+    if ortho:
+        raise NotImplementedError("orthographic cameras are not supported")
+    if absgrad:
+        raise NotImplementedError("absgrad is not supported (GsplatLoc: absgrad=False, model.py:124)")
+    if sparse_grad:
+        raise NotImplementedError("sparse_grad is not supported (GsplatLoc: sparse_grad=False, model.py:122)")
+
+    if sh_degree is None:
+        # treat colors as post-activation values, should be in shape [N, D] or [C, N, D]
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (
+            colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
+    else:
+        # treat colors as SH coefficients, should be in shape [N, K, 3] or [C, N, K, 3]
+        assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
+            colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+
+    # Project Gaussians to 2D.
+    radii, means2d, depths, conics, compensations = fully_fused_projection(
+        means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
+        calc_compensations=(rasterize_mode == "antialiased"),
+    )
+    opacities = opacities.repeat(C, 1)  # [C, N]
+    if compensations is not None:
+        opacities = opacities * compensations
+
+    meta.update({
+        "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
+        "conics": conics, "opacities": opacities,
+    })
+
+    # Turn colors into [C, N, D]
+    if sh_degree is None:
+        if colors.dim() == 2:
+            colors = colors.expand(C, -1, -1)
+    else:
+        camtoworlds = torch.inverse(viewmats)  # [C, 4, 4]
+        dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
+        masks = radii > 0  # [C, N]
+        if colors.dim() == 3:
+            shs = colors.expand(C, -1, -1, -1)  # [C, N, K, 3]
+        else:
+            shs = colors
+        colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3]
+        # make it apple-to-apple with Inria's CUDA Backend.
+        colors = torch.clamp_min(colors + 0.5, 0.0)
+
+    # Rasterize to pixels
+    if render_mode in ["RGB+D", "RGB+ED"]:
+        colors = torch.cat((colors, depths[..., None]), dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
+    elif render_mode in ["D", "ED"]:
+        colors = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
+    else:  # RGB
+        pass
+
+    # Identify intersecting tiles
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height, packed=False, n_cameras=C,
+    )
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+
+    meta.update({
+        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width,
+        "height": height, "tile_size": tile_size, "n_cameras": C,
+    })
+
+    if colors.shape[-1] > channel_chunk:
+        # slice into chunks
+        n_chunks = (colors.shape[-1] + channel_chunk - 1) // channel_chunk
+        render_colors, render_alphas = [], []
+        for i in range(n_chunks):
+            colors_chunk = colors[..., i * channel_chunk:(i + 1) * channel_chunk]
+            backgrounds_chunk = (backgrounds[..., i * channel_chunk:(i + 1) * channel_chunk]
+                                 if backgrounds is not None else None)
+            render_colors_, render_alphas_ = rasterize_to_pixels(
+                means2d, conics, colors_chunk, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+                backgrounds=backgrounds_chunk,
+            )
+            render_colors.append(render_colors_)
+            render_alphas.append(render_alphas_)
+        render_colors = torch.cat(render_colors, dim=-1)
+        render_alphas = render_alphas[0]  # discard the rest
+    else:
+        render_colors, render_alphas = rasterize_to_pixels(
+            means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
+            backgrounds=backgrounds,
+        )
+    if render_mode in ["ED", "RGB+ED"]:
+        # normalize the accumulated depth to get the expected depth
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+
+    return render_colors, render_alphas, meta

@@ -1,0 +1,134 @@
+/*
+ * gsloc_hip.h -- C ABI of libgsloc_hip.so: the MI355X (gfx950) Gaussian-splat
+ * rasterizer behind GsplatLoc's pose-tracking loop.
+ *
+ * Boundary being replaced.  The reference reaches this arithmetic through the
+ * third-party pybind11/torch extension `gsplat.csrc` (`_C`, IDX:14216 of
+ * /root/reference/.vscode/PythonImportHelper-v2-Completion.json) whose Python
+ * wrappers are called from /root/reference/src/my_gsplat/model.py:195-213 and
+ * /root/reference/src/my_gsplat/geometry.py:117-132.  Nothing C-callable exists
+ * in the reference; every entry point below names the gsplat operator (IDX line)
+ * whose work it performs, and INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *   - all floating point data is fp32, row-major, contiguous; indices are int32,
+ *     intersection keys int64;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *   - no allocation, no host synchronisation, no global state inside any call
+ *     (safe to capture in a hipGraph); scratch comes from the caller through the
+ *     `*_ws` arguments, sized by the matching `*_ws_bytes` query;
+ *   - return value: GSL_OK (0) or a negative gsl_status; the launch error of the
+ *     last kernel (hipGetLastError) is reported as GSL_ERR_HIP.
+ */
+#ifndef GSLOC_HIP_H
+#define GSLOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gsl_status {
+  GSL_OK = 0,
+  GSL_ERR_BAD_ARG = -1,   /* null pointer / non-positive size / unsupported channel count */
+  GSL_ERR_WORKSPACE = -2, /* workspace too small */
+  GSL_ERR_HIP = -3        /* HIP runtime reported an error for a launch */
+} gsl_status;
+
+/* Library identification: returns "gsloc_hip <version> gfx950". */
+const char* gsl_version(void);
+/* Text for a gsl_status. */
+const char* gsl_status_string(int status);
+
+/* ---- projection: gsplat.fully_fused_projection fwd/bwd (IDX:14351, IDX:14270) ----
+ * One camera.  viewmat[16] world->camera row-major, K[9] intrinsics, both on device.
+ * Outputs for culled Gaussians: radii = 0, other outputs 0.
+ * compensations may be NULL (rasterize_mode "classic"). */
+int gsl_project_fwd(const float* means, const float* quats, const float* scales,
+                    const float* viewmat, const float* K, int N, int width, int height,
+                    float eps2d, float near_plane, float far_plane, float radius_clip,
+                    int32_t* radii, float* means2d, float* depths, float* conics,
+                    float* compensations, void* stream);
+
+/* vjp of the above.  v_means/v_quats/v_scales may be NULL together (pose-only
+ * mode); v_viewmat may be NULL.  v_viewmat[16] is OVERWRITTEN with this camera's
+ * gradient (rows 0..2 used; row 3 zero).  v_compensations may be NULL.
+ * ws: gsl_project_bwd_ws_bytes(N) bytes. */
+size_t gsl_project_bwd_ws_bytes(int N);
+int gsl_project_bwd(const float* means, const float* quats, const float* scales,
+                    const float* viewmat, const float* K, int N, int width, int height,
+                    float eps2d, const int32_t* radii, const float* conics,
+                    const float* compensations, const float* v_means2d, const float* v_depths,
+                    const float* v_conics, const float* v_compensations, float* v_means,
+                    float* v_quats, float* v_scales, float* v_viewmat, void* ws, size_t ws_bytes,
+                    void* stream);
+
+/* ---- spherical harmonics: gsplat.spherical_harmonics fwd/bwd (IDX:14306, IDX:14297) ----
+ * dirs[M,3], coeffs[M,K,3] with K >= (degree+1)^2, masks[M] (uint8, may be NULL).
+ * degree 0..3.  v_dirs may be NULL. */
+int gsl_sh_fwd(int degree, const float* dirs, const float* coeffs, const uint8_t* masks, int M,
+               int K, float* colors, void* stream);
+int gsl_sh_bwd(int degree, const float* dirs, const float* coeffs, const uint8_t* masks, int M,
+               int K, const float* v_colors, float* v_coeffs, float* v_dirs, void* stream);
+
+/* ---- tile binning: gsplat.isect_tiles + isect_offset_encode (IDX:14360, IDX:14369) ----
+ * Tiles are tile_size x tile_size pixels; tile rows [ty0, ty1) of the tile_w x tile_h grid
+ * are binned (ty0=0, ty1=tile_h for the whole image; a strip for tile-parallel ranks).
+ * Tile ids in keys and offsets are GLOBAL (ty*tile_w+tx).
+ *
+ * gsl_isect_count: tiles_per_gauss[N] (may be NULL), tile_offsets[n_tiles+1] exclusive scan over
+ *   all tile_w*tile_h tiles (tiles outside the strip are empty), n_isects[1] = total.
+ *   ws: gsl_isect_ws_bytes(tile_w*tile_h).
+ * gsl_isect_fill: after gsl_isect_count with the same arguments.  Writes, for every tile,
+ *   its intersections sorted by (float32 depth bits, Gaussian index) ascending:
+ *   flatten_ids[I] and, if not NULL, isect_ids[I] = (cam_id << (32+tile_n_bits)) | (tile_id << 32) | depth bits.
+ *   sort_keys[capacity] is scratch (8 bytes per intersection).  Intersections with
+ *   position >= capacity are dropped (caller compares n_isects with capacity). */
+size_t gsl_isect_ws_bytes(int n_tiles);
+int gsl_isect_count(const float* means2d, const int32_t* radii, int N, int tile_size, int tile_w,
+                    int tile_h, int ty0, int ty1, int32_t* tiles_per_gauss, int32_t* tile_offsets,
+                    int32_t* n_isects, void* ws, size_t ws_bytes, void* stream);
+int gsl_isect_fill(const float* means2d, const int32_t* radii, const float* depths, int N,
+                   int tile_size, int tile_w, int tile_h, int ty0, int ty1, int cam_id,
+                   int tile_n_bits, const int32_t* tile_offsets, int64_t capacity,
+                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
+                   size_t ws_bytes, void* stream);
+
+/* Unsorted emit in Gaussian order (isect_tiles(sort=False)): cum_tiles[N] is the
+ * INCLUSIVE cumulative sum of tiles_per_gauss (int64). */
+int gsl_isect_emit(const float* means2d, const int32_t* radii, const float* depths,
+                   const int64_t* cum_tiles, int N, int tile_size, int tile_w, int tile_h,
+                   int cam_id, int tile_n_bits, int id_offset, int64_t* isect_ids,
+                   int32_t* flatten_ids, void* stream);
+
+/* Tile start offsets from sorted keys (isect_offset_encode): offsets[n_cameras*n_tiles]. */
+int gsl_isect_offsets(const int64_t* isect_ids, int64_t n_isects, int n_cameras, int n_tiles,
+                      int tile_n_bits, int32_t* offsets, void* stream);
+
+/* ---- compositing: gsplat.rasterize_to_pixels fwd/bwd (IDX:14378, IDX:14279) ----
+ * One camera.  channels in {1,2,3,4,5,8,16,32}.  tile_offsets[n_tiles+1] (global tile ids),
+ * flatten_ids index the per-Gaussian arrays directly.  Rows of tile rows [ty0,ty1) are
+ * rendered into full-size images (pixels outside the strip are left untouched).
+ * backgrounds[channels] may be NULL. */
+int gsl_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
+                      const float* opacities, const float* backgrounds, int channels, int width,
+                      int height, int tile_size, int tile_w, int tile_h, int ty0, int ty1,
+                      const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                      float* render_colors, float* render_alphas, int32_t* last_ids, void* stream);
+
+/* vjp.  v_* per-Gaussian outputs are ACCUMULATED INTO (caller zeroes them). */
+int gsl_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
+                      const float* opacities, const float* backgrounds, int channels, int width,
+                      int height, int tile_size, int tile_w, int tile_h, int ty0, int ty1,
+                      const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                      const float* render_alphas, const int32_t* last_ids,
+                      const float* v_render_colors, const float* v_render_alphas, float* v_means2d,
+                      float* v_conics, float* v_colors, float* v_opacities, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSLOC_HIP_H */

@@ -1,0 +1,270 @@
+"""GPU parity: every HIP stage operator (through the C ABI) against the CPU oracle.
+
+Tolerance (north_star): rendered depth and pose gradients within 1e-4 relative.
+Integer outputs (radii, tile counts, intersection keys, offsets) must be bit-exact
+when both sides are given the same fp32 inputs.  Discrete compositing decisions
+(alpha < 1/255, T <= 1e-4) can flip for a pixel that sits on a threshold, so image
+comparisons allow a small fraction of outlier pixels and say so.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gsplat_oracle as G
+from tests.scenes import random_scene, sh_from_rgb, small_pose
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _gpu():
+    import gsplatloc_amd as A
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return A
+
+
+def mostly_close(a, b, rtol=1e-4, atol=1e-5, max_bad_frac=0.0, what=""):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = (a - b).abs() > (atol + rtol * b.abs())
+    frac = bad.double().mean().item() if bad.numel() else 0.0
+    assert frac <= max_bad_frac, f"{what}: {frac:.2e} of elements differ (max |d|={float((a - b).abs().max()):.3e})"
+
+
+def rel_inf(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def _scene32(N=2000, W=160, H=120, **kw):
+    sc = random_scene(N, W, H, dtype=torch.float32, **kw)
+    return sc
+
+
+@pytest.mark.parametrize("aniso", [False, True])
+def test_projection_fwd_bwd(aniso):
+    A = _gpu()
+    sc = _scene32(3000, aniso=aniso, sigma_px=1.5)
+    W, H = sc["W"], sc["H"]
+    c2w = small_pose(2.0, 0.05, dtype=torch.float32)
+    V = torch.linalg.inv(c2w)[None]
+    Ks = sc["K"][None]
+    # oracle (fp32 on CPU)
+    mo, qo, so, Vo = (x.clone().requires_grad_() for x in (sc["means"], sc["quats"], sc["scales"], V))
+    r_o, m2_o, d_o, c_o, cp_o = G.fully_fused_projection(mo, qo, so, Vo, Ks, W, H, calc_compensations=True)
+    # HIP
+    mg, qg, sg, Vg = (x.to(DEV).clone().requires_grad_() for x in (sc["means"], sc["quats"], sc["scales"], V))
+    r_g, m2_g, d_g, c_g, cp_g = A.fully_fused_projection(mg, None, qg, sg, Vg, Ks.to(DEV), W, H,
+                                                         calc_compensations=True)
+    agree = (r_g.cpu() == r_o)
+    assert agree.float().mean() > 0.999, "radii must match except at ceil() borderlines"
+    keep = agree & (r_o > 0)
+    assert keep.sum() > 1000
+    for a, b, nm in ((m2_g, m2_o, "means2d"), (d_g, d_o, "depths"), (c_g, c_o, "conics"), (cp_g, cp_o, "comp")):
+        mostly_close(a.cpu()[keep], b[keep], rtol=1e-4, atol=1e-6, what=nm)
+    # culled entries are zero-filled
+    assert float(m2_g.cpu()[r_g.cpu() == 0].abs().max()) == 0.0
+    gen = torch.Generator().manual_seed(11)
+    vm2, vd, vc, vcp = (torch.randn(x.shape, generator=gen) * keep.float().reshape(keep.shape + (1,) * (x.dim() - 2))
+                        for x in (m2_o, d_o, c_o, cp_o))
+    ((m2_o * vm2).sum() + (d_o * vd).sum() + (c_o * vc).sum() + (cp_o * vcp).sum()).backward()
+    ((m2_g * vm2.to(DEV)).sum() + (d_g * vd.to(DEV)).sum() + (c_g * vc.to(DEV)).sum()
+     + (cp_g * vcp.to(DEV)).sum()).backward()
+    assert rel_inf(Vg.grad[0, :3], Vo.grad[0, :3]) < 1e-4, "v_viewmat"
+    assert float(Vg.grad[0, 3].abs().max()) == 0.0
+    mostly_close(mg.grad, mo.grad, rtol=2e-3, atol=1e-3 * float(mo.grad.abs().max()), what="v_means")
+    mostly_close(sg.grad, so.grad, rtol=2e-3, atol=1e-3 * float(so.grad.abs().max()), what="v_scales")
+    mostly_close(qg.grad, qo.grad, rtol=2e-3, atol=1e-3 * float(qo.grad.abs().max()) + 1e-7, what="v_quats")
+
+
+def test_projection_pose_only_matches_full():
+    A = _gpu()
+    sc = _scene32(2000, sigma_px=1.0)
+    V = torch.linalg.inv(small_pose(1.0, 0.02, dtype=torch.float32))[None].to(DEV)
+    K = sc["K"][None].to(DEV)
+    out = {}
+    for full in (True, False):
+        m = sc["means"].to(DEV).requires_grad_(full)
+        Vg = V.clone().requires_grad_()
+        r, m2, d, c, _ = A.fully_fused_projection(m, None, sc["quats"].to(DEV), sc["scales"].to(DEV), Vg, K, 160, 120)
+        ((m2 ** 2).sum() + (d * 0.3).sum() + c.sum()).backward()
+        out[full] = Vg.grad.clone()
+    assert torch.equal(out[True], out[False]), "pose-only mode must be bit-identical for v_viewmat"
+
+
+@pytest.mark.parametrize("shape", [(160, 120), (100, 70), (33, 17)])
+def test_binning_bit_exact(shape):
+    A = _gpu()
+    W, H = shape
+    sc = _scene32(4000, W, H, sigma_px=3.0)
+    V = torch.linalg.inv(small_pose(1.0, 0.02, dtype=torch.float32))[None]
+    r, m2, d, c, _ = G.fully_fused_projection(sc["means"], sc["quats"], sc["scales"], V, sc["K"][None], W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    for sort in (True, False):
+        tpg_o, ids_o, fl_o = G.isect_tiles(m2, r, d, 16, tw, th, sort=sort)
+        tpg_g, ids_g, fl_g = A.isect_tiles(m2.to(DEV), r.to(DEV), d.to(DEV), 16, tw, th, sort=sort)
+        assert torch.equal(tpg_g.cpu(), tpg_o)
+        assert torch.equal(ids_g.cpu(), ids_o), f"isect_ids sort={sort}"
+        assert torch.equal(fl_g.cpu(), fl_o), f"flatten_ids sort={sort}"
+    off_o = G.isect_offset_encode(ids_o if sort else ids_o, 1, tw, th)
+    tpg_o, ids_o, fl_o = G.isect_tiles(m2, r, d, 16, tw, th, sort=True)
+    off_o = G.isect_offset_encode(ids_o, 1, tw, th)
+    off_g = A.isect_offset_encode(ids_o.to(DEV), 1, tw, th)
+    assert torch.equal(off_g.cpu(), off_o)
+
+
+def test_binning_multi_camera_and_empty():
+    A = _gpu()
+    W, H = 96, 64
+    sc = _scene32(1500, W, H, sigma_px=2.0)
+    Vs = torch.stack([torch.linalg.inv(small_pose(a, 0.02, seed=s, dtype=torch.float32)) for a, s in ((0.5, 1), (3.0, 2))])
+    Ks = sc["K"][None].repeat(2, 1, 1)
+    r, m2, d, c, _ = G.fully_fused_projection(sc["means"], sc["quats"], sc["scales"], Vs, Ks, W, H)
+    tw, th = 6, 4
+    tpg_o, ids_o, fl_o = G.isect_tiles(m2, r, d, 16, tw, th)
+    tpg_g, ids_g, fl_g = A.isect_tiles(m2.to(DEV), r.to(DEV), d.to(DEV), 16, tw, th)
+    assert torch.equal(ids_g.cpu(), ids_o) and torch.equal(fl_g.cpu(), fl_o) and torch.equal(tpg_g.cpu(), tpg_o)
+    assert torch.equal(A.isect_offset_encode(ids_g, 2, tw, th).cpu(), G.isect_offset_encode(ids_o, 2, tw, th))
+    # nothing visible
+    r0 = torch.zeros_like(r)
+    tpg, ids, fl = A.isect_tiles(m2.to(DEV), r0.to(DEV), d.to(DEV), 16, tw, th)
+    assert ids.numel() == 0 and fl.numel() == 0 and int(tpg.sum()) == 0
+    off = A.isect_offset_encode(ids, 2, tw, th)
+    assert off.shape == (2, th, tw) and int(off.abs().sum()) == 0
+
+
+def test_binning_long_tile_list_uses_global_sort():
+    """> 8192 intersections in one tile exercises the global-memory sort path."""
+    A = _gpu()
+    N = 20000
+    g = torch.Generator().manual_seed(3)
+    m2 = (torch.rand(1, N, 2, generator=g) * 14 + 1).float()
+    r = torch.full((1, N), 1, dtype=torch.int32)
+    d = (torch.rand(1, N, generator=g) * 5 + 0.5).float()
+    d[0, ::7] = d[0, 3]  # depth ties: order falls back to the Gaussian index
+    tpg_o, ids_o, fl_o = G.isect_tiles(m2, r, d, 16, 2, 2)
+    tpg_g, ids_g, fl_g = A.isect_tiles(m2.to(DEV), r.to(DEV), d.to(DEV), 16, 2, 2)
+    assert ids_o.numel() == N
+    assert torch.equal(ids_g.cpu(), ids_o) and torch.equal(fl_g.cpu(), fl_o)
+
+
+def _stage_inputs(W, H, N, sigma_px, opacity, D, seed=5):
+    sc = _scene32(N, W, H, sigma_px=sigma_px, opacity=opacity)
+    V = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32))[None]
+    r, m2, d, c, _ = G.fully_fused_projection(sc["means"], sc["quats"], sc["scales"], V, sc["K"][None], W, H)
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    _, ids, fl = G.isect_tiles(m2, r, d, 16, tw, th)
+    offs = G.isect_offset_encode(ids, 1, tw, th)
+    gen = torch.Generator().manual_seed(seed)
+    cols = torch.rand(1, N, D, generator=gen)
+    cols[..., -1] = d  # last channel = depth, as in RGB+ED
+    return sc, m2, c, cols, sc["opacities"][None].contiguous(), offs, fl
+
+
+@pytest.mark.parametrize("D,opacity,sigma_px", [(1, None, 1.0), (4, None, 0.0), (4, (0.1, 0.9), 2.5), (3, (0.3, 1.0), 6.0),
+                                                 (7, (0.2, 0.8), 1.5)])
+def test_rasterize_fwd_bwd(D, opacity, sigma_px):
+    A = _gpu()
+    W, H, N = 100, 70, 3000
+    sc, m2, c, cols, opa, offs, fl = _stage_inputs(W, H, N, sigma_px, opacity, D)
+    bg = torch.rand(1, D, generator=torch.Generator().manual_seed(9)) if D == 3 else None
+    # float64 oracle on the SAME fp32 inputs
+    ins_o = [x.double().clone().requires_grad_() for x in (m2, c, cols, opa)]
+    rc_o, ra_o = G.rasterize_to_pixels(*ins_o, W, H, 16, offs, fl, backgrounds=bg.double() if bg is not None else None)
+    ins_g = [x.to(DEV).clone().requires_grad_() for x in (m2, c, cols, opa)]
+    rc_g, ra_g = A.rasterize_to_pixels(*ins_g, W, H, 16, offs.to(DEV), fl.to(DEV),
+                                       backgrounds=bg.to(DEV) if bg is not None else None)
+    assert rc_g.shape == (1, H, W, D) and ra_g.shape == (1, H, W, 1)
+    # a pixel exactly on the alpha / T thresholds may differ: allow 0.2 % outliers
+    mostly_close(rc_g, rc_o, rtol=1e-4, atol=1e-5, max_bad_frac=2e-3, what="render_colors")
+    mostly_close(ra_g, ra_o, rtol=1e-4, atol=1e-5, max_bad_frac=2e-3, what="render_alphas")
+    gen = torch.Generator().manual_seed(21)
+    v_c = torch.randn(rc_o.shape, generator=gen)
+    v_a = torch.randn(ra_o.shape, generator=gen)
+    ((rc_o * v_c.double()).sum() + (ra_o * v_a.double()).sum()).backward()
+    ((rc_g * v_c.to(DEV)).sum() + (ra_g * v_a.to(DEV)).sum()).backward()
+    for g_t, o_t, nm in zip(ins_g, ins_o, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
+        scale = float(o_t.grad.abs().max())
+        mostly_close(g_t.grad, o_t.grad, rtol=1e-3, atol=2e-4 * scale, max_bad_frac=5e-3, what=nm)
+        assert rel_inf(g_t.grad.sum(1), o_t.grad.sum(1)) < 5e-3, nm + " (summed)"
+
+
+def test_rasterize_empty_and_edge_tiles():
+    A = _gpu()
+    W, H = 37, 21  # ragged: partial tiles on both edges
+    m2 = torch.tensor([[[36.2, 20.1], [0.3, 0.2], [18.0, 10.0]]])
+    con = torch.tensor([[[0.5, 0.0, 0.5]] * 3])
+    col = torch.tensor([[[1.0], [2.0], [3.0]]])
+    opa = torch.tensor([[0.9, 0.8, 0.7]])
+    r = torch.tensor([[4, 4, 4]], dtype=torch.int32)
+    d = torch.tensor([[1.0, 2.0, 3.0]])
+    tw, th = 3, 2
+    _, ids, fl = G.isect_tiles(m2, r, d, 16, tw, th)
+    offs = G.isect_offset_encode(ids, 1, tw, th)
+    rc_o, ra_o = G.rasterize_to_pixels(m2.double(), con.double(), col.double(), opa.double(), W, H, 16, offs, fl)
+    rc_g, ra_g = A.rasterize_to_pixels(m2.to(DEV), con.to(DEV), col.to(DEV), opa.to(DEV), W, H, 16, offs.to(DEV),
+                                       fl.to(DEV))
+    mostly_close(rc_g, rc_o, what="edge colors")
+    mostly_close(ra_g, ra_o, what="edge alphas")
+    # no intersections at all
+    e_ids = torch.empty(0, dtype=torch.int64, device=DEV)
+    offs0 = A.isect_offset_encode(e_ids, 1, tw, th)
+    rc, ra = A.rasterize_to_pixels(m2.to(DEV), con.to(DEV), col.to(DEV), opa.to(DEV), W, H, 16, offs0,
+                                   torch.empty(0, dtype=torch.int32, device=DEV))
+    assert float(rc.abs().max()) == 0 and float(ra.abs().max()) == 0
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_spherical_harmonics(deg):
+    A = _gpu()
+    gen = torch.Generator().manual_seed(4)
+    M, K = 1000, 16
+    dirs = torch.randn(2, M, 3, generator=gen)
+    coeffs = torch.randn(2, M, K, 3, generator=gen)
+    masks = torch.rand(2, M, generator=gen) > 0.2
+    do, co = dirs.double().requires_grad_(), coeffs.double().requires_grad_()
+    out_o = G.spherical_harmonics(deg, do, co, masks)
+    dg, cg = dirs.to(DEV).requires_grad_(), coeffs.to(DEV).requires_grad_()
+    out_g = A.spherical_harmonics(deg, dg, cg, masks.to(DEV))
+    mostly_close(out_g, out_o, rtol=1e-4, atol=1e-5, what="sh colors")
+    v = torch.randn(out_o.shape, generator=gen)
+    (out_o * v.double()).sum().backward()
+    (out_g * v.to(DEV)).sum().backward()
+    mostly_close(cg.grad, co.grad, rtol=1e-4, atol=1e-5, what="v_coeffs")
+    mostly_close(dg.grad, do.grad, rtol=1e-3, atol=1e-4, what="v_dirs")
+
+
+@pytest.mark.parametrize("mode,sh", [("RGB+ED", 1), ("ED", 1), ("RGB", None), ("D", None), ("RGB+D", 1)])
+def test_rasterization_end_to_end(mode, sh):
+    """The exact keyword call of model.py:195-213 / geometry.py:117-132."""
+    A = _gpu()
+    W, H, N = 160, 120, 6000
+    sc = _scene32(N, W, H, sigma_px=1.2, opacity=(0.4, 1.0))
+    c2w = small_pose(0.5, 0.01, dtype=torch.float32)
+    colors = sh_from_rgb(sc["rgbs"]) if sh is not None else sc["rgbs"]
+    kw = dict(sh_degree=sh, width=W, height=H, packed=False, absgrad=False, sparse_grad=False, far_plane=1e10,
+              near_plane=1e-2, render_mode=mode, rasterize_mode="classic")
+    V = torch.linalg.inv(c2w)[None]
+    Vo = V.double().clone().requires_grad_()
+    rc_o, ra_o, _ = G.rasterization(sc["means"].double(), sc["quats"].double(), sc["scales"].double(),
+                                    sc["opacities"].double(), colors.double(), Vo, sc["K"].double()[None], **kw)
+    Vg = V.to(DEV).clone().requires_grad_()
+    rc_g, ra_g, meta = A.rasterization(means=sc["means"].to(DEV), quats=sc["quats"].to(DEV),
+                                       scales=sc["scales"].to(DEV), opacities=sc["opacities"].to(DEV),
+                                       colors=colors.to(DEV), viewmats=Vg, Ks=sc["K"][None].to(DEV), **kw)
+    assert rc_g.shape == rc_o.shape and ra_g.shape == ra_o.shape
+    mostly_close(rc_g, rc_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="render " + mode)
+    mostly_close(ra_g, ra_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="alpha " + mode)
+    for k in ("radii", "means2d", "depths", "conics", "opacities", "tiles_per_gauss", "isect_ids", "flatten_ids",
+              "isect_offsets", "tile_width", "tile_height", "width", "height", "tile_size", "n_cameras"):
+        assert k in meta
+    gen = torch.Generator().manual_seed(2)
+    v = torch.randn(rc_o.shape, generator=gen)
+    (rc_o * v.double()).sum().backward()
+    (rc_g * v.to(DEV)).sum().backward()
+    assert rel_inf(Vg.grad[0, :3], Vo.grad[0, :3]) < 2e-3, f"v_viewmat {mode}"
