@@ -33,12 +33,26 @@ _SIGNATURES = {
     "gsl_isect_count": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "gsl_isect_fill": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64,
                                P, P, P, P, c_size_t, P]),
+    "gsl_tile_sort": (c_int, [P, c_int, c_int, c_int64, P, P, P, c_int64, P]),
+    "gsl_fused_ws_bytes": (c_size_t, [c_int, c_int]),
+    "gsl_fused_project": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
+                                  c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t,
+                                  P]),
+    "gsl_fused_bin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P, P, P, P, c_size_t, P]),
+    "gsl_fused_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                     P, P, P, P]),
+    "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                     P, P, P, P, P, P, P]),
+    "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
+                                      P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "gsl_isect_offsets": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),
     "gsl_rasterize_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P,
                                   c_int64, P, P, P, P]),
+    "gsl_vacc_bytes": (c_size_t, [c_int, c_int]),
     "gsl_rasterize_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P,
-                                  c_int64, P, P, P, P, P, P, P, P, P]),
+                                  c_int64, P, P, P, P, P, P]),
+    "gsl_vacc_unpack": (c_int, [P, c_int, c_int, P, P, P, P, P]),
 }
 
 

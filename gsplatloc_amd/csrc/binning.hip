@@ -13,7 +13,7 @@
 
 namespace gsl {
 
-#define GSL_SORT_LDS_CAP 8192  // intersections per tile sorted in LDS (64 KiB); longer lists sort in global memory
+#define GSL_SORT_LDS_CAP 4096  // intersections per tile sorted in LDS (32 KiB); longer lists sort in global memory
 
 // Per-wave merged atomic add of 1 on ctr[key]: lanes holding the same key elect a leader.
 // Returns the position (old value + rank among equal lanes) for `active` lanes.
@@ -70,6 +70,85 @@ __global__ __launch_bounds__(256) void k_isect_count(const float* __restrict__ m
     int t = 0;
     if (act) t = (ymin + k / w) * tile_w + xmin + k % w;
     merged_atomic_inc(tile_counts, t, act);
+  }
+}
+
+// ---- LDS-privatised variants (strip of <= GSL_HIST_LDS_TILES tiles) -------------------------
+// Each 512-thread workgroup histograms its Gaussians' tiles in LDS (ds_add, no return) and
+// touches global memory once per distinct tile: for raster-ordered splats (one per pixel of the
+// previous depth frame) that is a few dozen atomics per workgroup instead of one per intersection.
+#define GSL_HIST_LDS_TILES 8192
+#define GSL_BIN_THREADS 512
+
+__device__ __forceinline__ void strip_rect(const float* __restrict__ means2d, const int32_t* __restrict__ radii, int i,
+                                           int N, int tile_size, int tile_w, int tile_h, int ty0, int ty1, int& xmin,
+                                           int& ymin, int& xmax, int& ymax) {
+  xmin = ymin = xmax = ymax = 0;
+  if (i < N) {
+    int r = radii[i];
+    if (r > 0) {
+      tile_rect(means2d[2 * (size_t)i], means2d[2 * (size_t)i + 1], r, tile_size, tile_w, tile_h, xmin, ymin, xmax,
+                ymax);
+      ymin = max(ymin, ty0);
+      ymax = min(ymax, ty1);
+      if (ymax < ymin) ymax = ymin;
+    }
+  }
+}
+
+__global__ __launch_bounds__(GSL_BIN_THREADS) void k_isect_count_lds(
+    const float* __restrict__ means2d, const int32_t* __restrict__ radii, int N, int tile_size, int tile_w, int tile_h,
+    int ty0, int ty1, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts) {
+  extern __shared__ int s_hist[];
+  int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
+  for (int k = threadIdx.x; k < nst; k += GSL_BIN_THREADS) s_hist[k] = 0;
+  __syncthreads();
+  int i = blockIdx.x * GSL_BIN_THREADS + threadIdx.x;
+  int xmin, ymin, xmax, ymax;
+  strip_rect(means2d, radii, i, N, tile_size, tile_w, tile_h, ty0, ty1, xmin, ymin, xmax, ymax);
+  if (i < N && tiles_per_gauss) tiles_per_gauss[i] = (xmax - xmin) * (ymax - ymin);
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) atomicAdd(&s_hist[y * tile_w + x - tbase], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nst; k += GSL_BIN_THREADS) {
+    int c = s_hist[k];
+    if (c) atomicAdd(&tile_counts[tbase + k], c);
+  }
+}
+
+__global__ __launch_bounds__(GSL_BIN_THREADS) void k_isect_scatter_lds(
+    const float* __restrict__ means2d, const int32_t* __restrict__ radii, const float* __restrict__ depths, int N,
+    int tile_size, int tile_w, int tile_h, int ty0, int ty1, const int32_t* __restrict__ tile_offsets,
+    int32_t* __restrict__ cursors, long long capacity, uint64_t* __restrict__ keys) {
+  extern __shared__ int s_mem[];
+  int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
+  int* s_cnt = s_mem;
+  int* s_base = s_mem + nst;
+  for (int k = threadIdx.x; k < nst; k += GSL_BIN_THREADS) s_cnt[k] = 0;
+  __syncthreads();
+  int i = blockIdx.x * GSL_BIN_THREADS + threadIdx.x;
+  int xmin, ymin, xmax, ymax;
+  strip_rect(means2d, radii, i, N, tile_size, tile_w, tile_h, ty0, ty1, xmin, ymin, xmax, ymax);
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) atomicAdd(&s_cnt[y * tile_w + x - tbase], 1);
+  __syncthreads();
+  // one returning global atomic per distinct tile reserves this workgroup's span of the bucket
+  for (int k = threadIdx.x; k < nst; k += GSL_BIN_THREADS) {
+    int c = s_cnt[k];
+    if (c) {
+      s_base[k] = tile_offsets[tbase + k] + atomicAdd(&cursors[tbase + k], c);
+      s_cnt[k] = 0;
+    }
+  }
+  __syncthreads();
+  if (xmax > xmin && ymax > ymin) {
+    uint64_t key = ((uint64_t)__float_as_uint(depths[i]) << 32) | (uint32_t)i;
+    for (int y = ymin; y < ymax; ++y)
+      for (int x = xmin; x < xmax; ++x) {
+        int lt = y * tile_w + x - tbase;
+        long long pos = (long long)s_base[lt] + atomicAdd(&s_cnt[lt], 1);
+        if (pos < capacity) keys[pos] = key;
+      }
   }
 }
 
@@ -149,7 +228,8 @@ __global__ __launch_bounds__(256) void k_isect_scatter(const float* __restrict__
 }
 
 // Ascending-only bitonic network on n (arbitrary) 64-bit keys; comparators whose upper index
-// falls past n are skipped (equivalent to +inf padding).  Works on LDS or global memory.
+// falls past n are skipped (equivalent to +inf padding).  Generic version (any memory), one
+// workgroup barrier per sub-step: used for lists too long for LDS.
 __device__ __forceinline__ void bitonic_sort(uint64_t* a, int n, int tid, int nthreads) {
   int P = 1;
   while (P < n) P <<= 1;
@@ -181,6 +261,59 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* a, int n, int tid, int nt
   }
 }
 
+// LDS version for a 256-thread workgroup.  Each of `nw` working waves owns a contiguous segment
+// of S = P/nw keys; every sub-step whose comparator block fits inside a segment needs no
+// workgroup barrier (a wave's LDS operations complete in order), which leaves 2-5 s_barriers
+// per sort instead of log^2(P)/2.
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  if (P < 2) return;
+  int nw = P >= 512 ? 4 : (P >= 256 ? 2 : 1);
+  int S = P / nw;           // keys per wave segment
+  int pairs_w = S >> 1;     // comparators per wave per sub-step
+  int wv = tid >> 6, lane = tid & 63;
+  bool work = wv < nw;
+  int pbase = wv * pairs_w;
+  for (int k = 2; k <= P; k <<= 1) {
+    int hk = k >> 1;
+    if (work) {
+      for (int q = lane; q < pairs_w; q += 64) {
+        int i = pbase + q;
+        int blk = i / hk, off = i - blk * hk;
+        int lo = blk * k + off;
+        int hi = blk * k + (k - 1 - off);
+        if (hi < n) {
+          uint64_t x = a[lo], y = a[hi];
+          if (x > y) { a[lo] = y; a[hi] = x; }
+        }
+      }
+    }
+    if (k > S) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    for (int j = hk >> 1; j >= 1; j >>= 1) {
+      if (work) {
+        for (int q = lane; q < pairs_w; q += 64) {
+          int i = pbase + q;
+          int blk = i / j, off = i - blk * j;
+          int lo = blk * 2 * j + off;
+          int hi = lo + j;
+          if (hi < n) {
+            uint64_t x = a[lo], y = a[hi];
+            if (x > y) { a[lo] = y; a[hi] = x; }
+          }
+        }
+      }
+      // the NEXT sub-step (distance j/2, or the next stage's mirror over k*2) decides the fence:
+      // a barrier is needed whenever this or the next sub-step crosses segments
+      bool cross = (2 * j > S) || (j > 1 ? (j > S) : (2 * k > S));
+      if (cross) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    }
+  }
+  __syncthreads();
+}
+
 // One workgroup per tile: sort the tile's bucket, write flatten_ids (+ gsplat-style isect_ids).
 __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ tile_offsets, int tile_begin,
                                                    long long capacity, uint64_t* __restrict__ keys,
@@ -197,7 +330,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
   if (n <= GSL_SORT_LDS_CAP) {
     for (int i = tid; i < n; i += 256) skeys[i] = src[i];
     __syncthreads();
-    if (n > 1) bitonic_sort(skeys, n, tid, 256);
+    bitonic_sort_lds(skeys, n, tid);
     for (int i = tid; i < n; i += 256) {
       uint64_t k = skeys[i];
       flatten_ids[s + i] = (int32_t)(uint32_t)k;
@@ -286,8 +419,15 @@ extern "C" int gsl_isect_count(const float* means2d, const int32_t* radii, int N
   int32_t* cursors = counts + n_tiles;
   if (hipMemsetAsync(counts, 0, (size_t)n_tiles * sizeof(int32_t), st) != hipSuccess) return GSL_ERR_HIP;
   if (N > 0) {
-    hipLaunchKernelGGL(gsl::k_isect_count, dim3((N + 255) / 256), dim3(256), 0, st, means2d, radii, N, tile_size,
-                       tile_w, tile_h, ty0, ty1, tiles_per_gauss, counts);
+    int nst = (ty1 - ty0) * tile_w;
+    if (nst > 0 && nst <= GSL_HIST_LDS_TILES) {
+      hipLaunchKernelGGL(gsl::k_isect_count_lds, dim3((N + GSL_BIN_THREADS - 1) / GSL_BIN_THREADS),
+                         dim3(GSL_BIN_THREADS), (size_t)nst * sizeof(int), st, means2d, radii, N, tile_size, tile_w,
+                         tile_h, ty0, ty1, tiles_per_gauss, counts);
+    } else {
+      hipLaunchKernelGGL(gsl::k_isect_count, dim3((N + 255) / 256), dim3(256), 0, st, means2d, radii, N, tile_size,
+                         tile_w, tile_h, ty0, ty1, tiles_per_gauss, counts);
+    }
     GSL_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(gsl::k_tile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors);
@@ -308,13 +448,29 @@ extern "C" int gsl_isect_fill(const float* means2d, const int32_t* radii, const 
   if (!ws || ws_bytes < gsl_isect_ws_bytes(n_tiles)) return GSL_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   int32_t* cursors = (int32_t*)ws + n_tiles;
-  hipLaunchKernelGGL(gsl::k_isect_scatter, dim3((N + 255) / 256), dim3(256), 0, st, means2d, radii, depths, N,
-                     tile_size, tile_w, tile_h, ty0, ty1, tile_offsets, cursors, (long long)capacity, sort_keys);
+  int nst = (ty1 - ty0) * tile_w;
+  if (nst <= GSL_HIST_LDS_TILES) {
+    hipLaunchKernelGGL(gsl::k_isect_scatter_lds, dim3((N + GSL_BIN_THREADS - 1) / GSL_BIN_THREADS),
+                       dim3(GSL_BIN_THREADS), (size_t)2 * nst * sizeof(int), st, means2d, radii, depths, N, tile_size,
+                       tile_w, tile_h, ty0, ty1, tile_offsets, cursors, (long long)capacity, sort_keys);
+  } else {
+    hipLaunchKernelGGL(gsl::k_isect_scatter, dim3((N + 255) / 256), dim3(256), 0, st, means2d, radii, depths, N,
+                       tile_size, tile_w, tile_h, ty0, ty1, tile_offsets, cursors, (long long)capacity, sort_keys);
+  }
   GSL_CHECK_LAUNCH();
   int64_t cam_enc = (int64_t)cam_id << (32 + tile_n_bits);
-  int strip_tiles = (ty1 - ty0) * tile_w;
-  hipLaunchKernelGGL(gsl::k_tile_sort, dim3(strip_tiles), dim3(256), 0, st, tile_offsets, ty0 * tile_w,
-                     (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc);
+  return gsl_tile_sort(tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w, capacity, sort_keys, flatten_ids, isect_ids,
+                       cam_enc, stream);
+}
+
+extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+                             uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
+                             void* stream) {
+  if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
+  if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
+  if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

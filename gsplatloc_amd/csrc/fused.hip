@@ -1,0 +1,889 @@
+// Fused single-camera render pipeline for GsplatLoc's pose-tracking loop (the hot path):
+//   forward : project + SH colour + pack + tile histogram  -> scan -> scatter -> per-tile LDS sort
+//             -> composite (expected-depth normalisation fused)
+//   backward: composite vjp (packed 64-byte gradient rows)  -> projection/SH vjp + pose reduction
+// Same arithmetic as the stage operators (project.hip / binning.hip / raster.hip / sh.hip), which
+// restate gsplat.rasterization (IDX:14954) as called from /root/reference/src/my_gsplat/model.py:195-213;
+// the difference is data layout and launch count.
+//
+// HBM layout (SoA of 16-byte records, one per Gaussian, written once by the projection kernel and
+// gathered by the compositing kernels with one or two dwordx4 loads):
+//   Q0 = (x, y, depth, opacity_eff)   Q1 = (conic_a, conic_b, conic_c, r_cull)   Q2 = (r, g, b, 0)
+// r_cull is a conservative radius of the alpha >= 1/255 region, used by the per-quadrant ballot test.
+// gsplat's meta tensors (means2d, depths, conics, opacities) are strided views of Q0/Q1 on the host.
+#include "project_dev.h"
+#include "sh_dev.h"
+
+namespace gsl {
+
+#define GSL_F_BIN_THREADS 512
+#define GSL_F_MAX_STRIP_TILES 8192
+
+__device__ __forceinline__ float cull_radius(float ca, float cb, float cc, float op) {
+  float tau = __logf(255.f * op) * 1.01f + 0.01f;
+  float det = ca * cc - cb * cb;
+  if (!(tau > 0.f)) return -1.f;  // opacity < 1/255: can never reach the alpha threshold
+  if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 1e30f;  // degenerate conic: never cull
+  float inv = 2.f * tau / det;
+  return sqrtf(inv * fmaxf(ca, cc)) * 1.0001f + 1e-3f;
+}
+
+// Inverse of the rotation block and the camera position -R^-1 t (what torch.inverse(viewmat)[:3,3] is).
+__device__ __forceinline__ void cam_inverse(const Cam& cam, M3& Ri, float cp[3]) {
+  const M3& R = cam.R;
+  float c00 = R(1, 1) * R(2, 2) - R(1, 2) * R(2, 1);
+  float c01 = R(1, 2) * R(2, 0) - R(1, 0) * R(2, 2);
+  float c02 = R(1, 0) * R(2, 1) - R(1, 1) * R(2, 0);
+  float det = R(0, 0) * c00 + R(0, 1) * c01 + R(0, 2) * c02;
+  float id = 1.f / det;
+  Ri(0, 0) = c00 * id; Ri(1, 0) = c01 * id; Ri(2, 0) = c02 * id;
+  Ri(0, 1) = (R(0, 2) * R(2, 1) - R(0, 1) * R(2, 2)) * id;
+  Ri(1, 1) = (R(0, 0) * R(2, 2) - R(0, 2) * R(2, 0)) * id;
+  Ri(2, 1) = (R(0, 1) * R(2, 0) - R(0, 0) * R(2, 1)) * id;
+  Ri(0, 2) = (R(0, 1) * R(1, 2) - R(0, 2) * R(1, 1)) * id;
+  Ri(1, 2) = (R(0, 2) * R(1, 0) - R(0, 0) * R(1, 2)) * id;
+  Ri(2, 2) = (R(0, 0) * R(1, 1) - R(0, 1) * R(1, 0)) * id;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cp[k] = -(Ri(k, 0) * cam.t[0] + Ri(k, 1) * cam.t[1] + Ri(k, 2) * cam.t[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward 1: projection + colour + pack + tile histogram.
+// ------------------------------------------------------------------------------------------------
+template <bool RGB>
+__global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
+    const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ opacities, const float* __restrict__ colors, int sh_degree, int K_sh,
+    const float* __restrict__ V, const float* __restrict__ Kmat, int N, int W, int H, float eps2d, float near_plane,
+    float far_plane, float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
+    int32_t* __restrict__ radii, float4* __restrict__ Q0, float4* __restrict__ Q1, float4* __restrict__ Q2,
+    float* __restrict__ comps, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts) {
+  extern __shared__ int s_hist[];
+  int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
+  for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) s_hist[k] = 0;
+  __syncthreads();
+  int i = blockIdx.x * GSL_F_BIN_THREADS + threadIdx.x;
+  Cam cam = load_cam(V, Kmat);
+  int xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+  if (i < N) {
+    ProjMid p;
+    float q[4], s[3];
+    load_gaussian(means, quats, scales, i, cam, p, q, s);
+    int radius = 0;
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = make_float4(0.f, 0.f, 0.f, -1.f);
+    float comp = 0.f;
+    if (p.mc[2] >= near_plane && p.mc[2] <= far_plane) {
+      p.covar = quat_scale_to_covar(q, s);
+      p.covar_c = mul_bt(mul(cam.R, p.covar), cam.R);
+      persp_mid(cam, W, H, p);
+      float a, b, c;
+      cov2d_from(p.J, p.covar_c, a, b, c);
+      float det_orig = a * c - b * b;
+      a += eps2d;
+      c += eps2d;
+      float det = a * c - b * b;
+      if (det > 0.f) {
+        float bb = 0.5f * (a + c);
+        float v1 = bb + sqrtf(fmaxf(0.01f, bb * bb - det));
+        float rad = ceilf(3.f * sqrtf(v1));
+        float mx = cam.fx * p.mc[0] * p.rz + cam.cx;
+        float my = cam.fy * p.mc[1] * p.rz + cam.cy;
+        bool ok = rad > radius_clip;
+        ok = ok && !(mx + rad <= 0.f || mx - rad >= (float)W || my + rad <= 0.f || my - rad >= (float)H);
+        if (ok) {
+          float inv = 1.f / det;
+          radius = (int)rad;
+          comp = sqrtf(fmaxf(0.f, det_orig / det));
+          float op = opacities[i];
+          if (antialiased) op *= comp;
+          float ca = c * inv, cb = -b * inv, cc = a * inv;
+          o0 = make_float4(mx, my, p.mc[2], op);
+          o1 = make_float4(ca, cb, cc, cull_radius(ca, cb, cc, op));
+        }
+      }
+    }
+    radii[i] = radius;
+    Q0[i] = o0;
+    Q1[i] = o1;
+    if (comps) comps[i] = comp;
+    if (RGB) {
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      if (sh_degree < 0) {
+        c0 = colors[3 * (size_t)i]; c1 = colors[3 * (size_t)i + 1]; c2 = colors[3 * (size_t)i + 2];
+      } else {
+        if (radius > 0) {  // masks = radii > 0
+          M3 Ri;
+          float cp[3];
+          cam_inverse(cam, Ri, cp);
+          float x = p.mean[0] - cp[0], y = p.mean[1] - cp[1], z = p.mean[2] - cp[2];
+          float inorm = rsqrtf(x * x + y * y + z * z);
+          float Y[16];
+          sh_basis(sh_degree, x * inorm, y * inorm, z * inorm, Y);
+          int nK = (sh_degree + 1) * (sh_degree + 1);
+          const float* cf = colors + (size_t)i * K_sh * 3;
+          for (int k = 0; k < nK; ++k) {
+            c0 += Y[k] * cf[3 * k]; c1 += Y[k] * cf[3 * k + 1]; c2 += Y[k] * cf[3 * k + 2];
+          }
+        }
+        c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
+      }
+      Q2[i] = make_float4(c0, c1, c2, 0.f);
+    }
+    if (radius > 0) {
+      tile_rect(o0.x, o0.y, radius, 16, tile_w, tile_h, xmin, ymin, xmax, ymax);
+      ymin = max(ymin, ty0);
+      ymax = min(ymax, ty1);
+      if (ymax < ymin) ymax = ymin;
+    }
+    if (tiles_per_gauss) tiles_per_gauss[i] = (xmax - xmin) * (ymax - ymin);
+  }
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) atomicAdd(&s_hist[y * tile_w + x - tbase], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) {
+    int c = s_hist[k];
+    if (c) atomicAdd(&tile_counts[tbase + k], c);
+  }
+}
+
+// Exclusive scan of tile counts (single workgroup) -> offsets[n+1], total, zeroed cursors.
+__global__ __launch_bounds__(1024) void k_ftile_scan(const int32_t* __restrict__ counts, int n,
+                                                     int32_t* __restrict__ offsets, int32_t* __restrict__ n_isects,
+                                                     int32_t* __restrict__ cursors) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + tid;
+    int v = (i < n) ? counts[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    int carry = carry_s;
+    if (i < n) {
+      offsets[i] = carry + woff + x - v;
+      cursors[i] = 0;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    offsets[n] = carry_s;
+    n_isects[0] = carry_s;
+  }
+}
+
+// Forward 2: scatter (depth bits | Gaussian id) keys into the tile buckets.
+__global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
+    const float4* __restrict__ Q0, const int32_t* __restrict__ radii, int N, int tile_w, int tile_h, int ty0, int ty1,
+    const int32_t* __restrict__ tile_offsets, int32_t* __restrict__ cursors, long long capacity,
+    uint64_t* __restrict__ keys) {
+  extern __shared__ int s_mem[];
+  int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
+  int* s_cnt = s_mem;
+  int* s_base = s_mem + nst;
+  for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) s_cnt[k] = 0;
+  __syncthreads();
+  int i = blockIdx.x * GSL_F_BIN_THREADS + threadIdx.x;
+  int xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+  uint64_t key = 0;
+  if (i < N) {
+    int r = radii[i];
+    if (r > 0) {
+      float4 q0 = Q0[i];
+      tile_rect(q0.x, q0.y, r, 16, tile_w, tile_h, xmin, ymin, xmax, ymax);
+      ymin = max(ymin, ty0);
+      ymax = min(ymax, ty1);
+      if (ymax < ymin) ymax = ymin;
+      key = ((uint64_t)__float_as_uint(q0.z) << 32) | (uint32_t)i;
+    }
+  }
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) atomicAdd(&s_cnt[y * tile_w + x - tbase], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) {
+    int c = s_cnt[k];
+    if (c) {
+      s_base[k] = tile_offsets[tbase + k] + atomicAdd(&cursors[tbase + k], c);
+      s_cnt[k] = 0;
+    }
+  }
+  __syncthreads();
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) {
+      int lt = y * tile_w + x - tbase;
+      long long pos = (long long)s_base[lt] + atomicAdd(&s_cnt[lt], 1);
+      if (pos < capacity) keys[pos] = key;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compositing.  256-thread workgroup per 16x16 tile, one wave64 per 8x8 quadrant.  A batch of
+// 256 splats is gathered once per workgroup into LDS; each wave then pulls 64 of them into
+// registers (one per lane), ballots the quadrant test and broadcasts the survivors lane by lane
+// with v_readlane (scalar operands) -- the per-splat inner loop touches neither LDS nor memory.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+template <int D>
+struct FStage {
+  float4 s0[256];
+  float4 s1[256];
+  float4 s2[(D >= 3) ? 256 : 1];
+};
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_fraster_fwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+  constexpr bool RGB = D >= 3;
+  constexpr bool DEPTH = (D == 1) || (D == 4);
+  __shared__ FStage<D> sb;
+  int tile = ty0 * tile_w + blockIdx.x;
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+  bool done = !inside;
+  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;  // quadrant centre; half extent of pixel centres = 3.5
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs > re) rs = re;
+  int nb = (int)((re - rs + 255) / 256);
+
+  float T = 1.f;
+  int cur_idx = 0;
+  float pix[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pix[k] = 0.f;
+
+  for (int b = 0; b < nb; ++b) {
+    if (__syncthreads_and(done)) break;
+    long long bstart = rs + (long long)b * 256;
+    int bsize = (int)min((long long)256, re - bstart);
+    if (tid < bsize) {
+      int g = flatten_ids[bstart + tid];
+      sb.s0[tid] = Q0[g];
+      sb.s1[tid] = Q1[g];
+      if (RGB) sb.s2[tid] = Q2[g];
+    }
+    __syncthreads();
+    bool wdone = __all(done);
+    for (int c = 0; c < bsize && !wdone; c += 64) {
+      int e = c + lane;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f), a2 = a0;
+      if (e < bsize) {
+        a0 = sb.s0[e];
+        a1 = sb.s1[e];
+        if (RGB) a2 = sb.s2[e];
+      }
+      bool hit = (fabsf(a0.x - qcx) <= a1.w + 3.5f) && (fabsf(a0.y - qcy) <= a1.w + 3.5f);
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        float sx = bcast(a0.x, l), sy = bcast(a0.y, l), sop = bcast(a0.w, l);
+        float sa = bcast(a1.x, l), sbb = bcast(a1.y, l), sc = bcast(a1.z, l);
+        float dx = sx - px, dy = sy - py;
+        float sigma = 0.5f * (sa * dx * dx + sc * dy * dy) + sbb * dx * dy;
+        float alpha = fminf(GSL_ALPHA_MAX, sop * __expf(-sigma));
+        bool ok = !done && (sigma >= 0.f) && (alpha >= GSL_ALPHA_MIN);
+        float nT = T * (1.f - alpha);
+        bool stop = ok && (nT <= GSL_T_STOP);
+        bool take = ok && !stop;
+        float vis = take ? alpha * T : 0.f;
+        if (RGB) {
+          pix[0] += bcast(a2.x, l) * vis;
+          pix[1] += bcast(a2.y, l) * vis;
+          pix[2] += bcast(a2.z, l) * vis;
+        }
+        if (DEPTH) pix[D - 1] += bcast(a0.z, l) * vis;
+        cur_idx = take ? (int)bstart + c + l : cur_idx;
+        T = take ? nT : T;
+        done = done || stop;
+        if (__all(done)) { wdone = true; break; }
+      }
+    }
+  }
+  if (inside) {
+    size_t pid = (size_t)i * W + j;
+    float A = 1.f - T;
+    alphas[pid] = A;
+    if (ED) pix[D - 1] = pix[D - 1] / fmaxf(A, 1e-10f);
+#pragma unroll
+    for (int k = 0; k < D; ++k) render[pid * D + k] = pix[k];
+    last_ids[pid] = cur_idx;
+  }
+}
+
+// 64-lane reduce-scatter of 32 per-lane values: after the call lanes 2v and 2v+1 both hold the
+// wave-wide sum of v[index v].  Steps: permlane32/16 swaps (cross-row), then DPP row mirrors and
+// quad permutes; 16+8 swaps, 24+4+2+1 adds/selects instead of 32 x 6 DPP adds.
+__device__ __forceinline__ float swap_add32(float lo_keep, float hi_keep) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo_keep),
+                                            __builtin_bit_cast(unsigned, hi_keep), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float swap_add16(float lo_keep, float hi_keep) {
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, lo_keep),
+                                            __builtin_bit_cast(unsigned, hi_keep), false, false);
+  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float reduce_scatter32(float (&v)[32], int lane) {
+  float a[16], b[8], c[4], d[2];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a[k] = swap_add32(v[k], v[16 + k]);  // lanes <32: idx k, lanes >=32: idx 16+k
+#pragma unroll
+  for (int k = 0; k < 8; ++k) b[k] = swap_add16(a[k], a[8 + k]);    // odd rows keep the upper half
+  bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float lo = b[k] + dpp_get<0x140>(b[k]);          // row_mirror pairs lane i with 15-i
+    float hi = b[4 + k] + dpp_get<0x140>(b[4 + k]);
+    c[k] = b3 ? hi : lo;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float lo = c[k] + dpp_get<0x141>(c[k]);          // row_half_mirror pairs i with 7-i (per 8 lanes)
+    float hi = c[2 + k] + dpp_get<0x141>(c[2 + k]);
+    d[k] = b2 ? hi : lo;
+  }
+  float lo = d[0] + dpp_get<0x4E>(d[0]);             // quad_perm [2,3,0,1]
+  float hi = d[1] + dpp_get<0x4E>(d[1]);
+  float r = b1 ? hi : lo;
+  r += dpp_get<0xB1>(r);                             // quad_perm [1,0,3,2]
+  return r;
+}
+
+template <int D>
+struct FStageB {
+  static constexpr int A = 6 + D;   // v_xy 2, v_conic 3, v_opacity 1, v_colour D
+  static constexpr int AP = A | 1;  // odd LDS pitch
+  float4 s0[256];
+  float4 s1[256];
+  float4 s2[(D >= 3) ? 256 : 1];
+  int32_t id[256];
+  float acc[256 * AP];
+  uint16_t list[4][64];
+};
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_fraster_bwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+    float* __restrict__ vacc) {
+  constexpr bool RGB = D >= 3;
+  constexpr bool DEPTH = (D == 1) || (D == 4);
+  constexpr int A = FStageB<D>::A;
+  constexpr int AP = FStageB<D>::AP;
+  constexpr int G = 32 / A;  // splats reduced per reduce-scatter
+  __shared__ FStageB<D> sb;
+  __shared__ int s_final[4];
+  int tile = ty0 * tile_w + blockIdx.x;
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs >= re) return;
+
+  size_t pid = inside ? ((size_t)i * W + j) : 0;
+  float Aimg = inside ? alphas[pid] : 0.f;
+  float T_final = 1.f - Aimg;
+  float T = T_final;
+  int bin_final = inside ? last_ids[pid] : -1;
+  float vc[D], buf[D];
+  float va = inside ? v_alphas[pid] : 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    vc[k] = inside ? v_render[pid * D + k] : 0.f;
+    buf[k] = 0.f;
+  }
+  if (ED && inside) {
+    // render[..., D-1] = C_depth / max(A, 1e-10): chain to the accumulated depth and to alpha
+    float dn = render[pid * D + (D - 1)];
+    float vd = vc[D - 1];
+    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
+    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
+  }
+  int wave_final = bin_final;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
+  if (lane == 0) s_final[wv] = wave_final;
+  __syncthreads();
+  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
+  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (rs >= re) return;
+  int nb = (int)((re - rs + 255) / 256);
+
+  for (int b = 0; b < nb; ++b) {
+    long long bend = re - 1 - (long long)b * 256;  // slot t <-> absolute index bend - t (back to front)
+    int bsize = (int)min((long long)256, bend + 1 - rs);
+    __syncthreads();
+    if (tid < bsize) {
+      int g = flatten_ids[bend - tid];
+      sb.id[tid] = g;
+      sb.s0[tid] = Q0[g];
+      sb.s1[tid] = Q1[g];
+      if (RGB) sb.s2[tid] = Q2[g];
+    }
+#pragma unroll
+    for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
+    __syncthreads();
+    int t_first = (int)max((long long)0, bend - (long long)wave_final);
+    for (int c = (t_first / 64) * 64; c < bsize; c += 64) {
+      int e = c + lane;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f), a2 = a0;
+      if (e < bsize && e >= t_first) {
+        a0 = sb.s0[e];
+        a1 = sb.s1[e];
+        if (RGB) a2 = sb.s2[e];
+      }
+      bool hit = (fabsf(a0.x - qcx) <= a1.w + 3.5f) && (fabsf(a0.y - qcy) <= a1.w + 3.5f);
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        float vals[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) vals[k] = 0.f;
+        int slot[G];
+#pragma unroll
+        for (int h = 0; h < G; ++h) {
+          slot[h] = -1;
+          // next hit this wave actually touches
+          bool found = false;
+          int l = 0;
+          bool valid = false;
+          float dx = 0.f, dy = 0.f, sa = 0.f, sbb = 0.f, sc = 0.f, sop = 0.f, vis = 0.f, alpha = 0.f;
+          while (m && !found) {
+            l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            float sx = bcast(a0.x, l), sy = bcast(a0.y, l);
+            sop = bcast(a0.w, l);
+            sa = bcast(a1.x, l); sbb = bcast(a1.y, l); sc = bcast(a1.z, l);
+            dx = sx - px; dy = sy - py;
+            float sigma = 0.5f * (sa * dx * dx + sc * dy * dy) + sbb * dx * dy;
+            vis = __expf(-sigma);
+            alpha = fminf(GSL_ALPHA_MAX, sop * vis);
+            valid = inside && ((bend - (c + l)) <= (long long)bin_final) && (sigma >= 0.f) &&
+                    (alpha >= GSL_ALPHA_MIN);
+            found = __any(valid);
+          }
+          if (!found) continue;
+          slot[h] = c + l;
+          float colv[D];
+          if (RGB) { colv[0] = bcast(a2.x, l); colv[1] = bcast(a2.y, l); colv[2] = bcast(a2.z, l); }
+          if (DEPTH) colv[D - 1] = bcast(a0.z, l);
+          if (valid) {
+            float ra = 1.f / (1.f - alpha);
+            T *= ra;
+            float fac = alpha * T;
+            float v_alpha = 0.f;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+              vals[h * A + 6 + k] = fac * vc[k];
+              v_alpha += (colv[k] * T - buf[k] * ra) * vc[k];
+              buf[k] += colv[k] * fac;
+            }
+            v_alpha += T_final * ra * va;
+            if (sop * vis <= GSL_ALPHA_MAX) {
+              float v_sigma = -sop * vis * v_alpha;
+              vals[h * A + 0] = v_sigma * (sa * dx + sbb * dy);
+              vals[h * A + 1] = v_sigma * (sbb * dx + sc * dy);
+              vals[h * A + 2] = 0.5f * v_sigma * dx * dx;
+              vals[h * A + 3] = v_sigma * dx * dy;
+              vals[h * A + 4] = 0.5f * v_sigma * dy * dy;
+              vals[h * A + 5] = vis * v_alpha;
+            }
+          }
+        }
+        if (slot[0] < 0) break;  // no touched splat left in this chunk
+        float r = reduce_scatter32(vals, lane);
+        int v = lane >> 1, h = v / A, k = v - h * A;
+        int sl = -1;
+#pragma unroll
+        for (int hh = 0; hh < G; ++hh) sl = (h == hh) ? slot[hh] : sl;
+        if (!(lane & 1) && h < G && sl >= 0) atomicAdd(&sb.acc[sl * AP + k], r);
+      }
+    }
+    __syncthreads();
+    // Flush the batch: pack non-zero slots so that 16 consecutive lanes add one Gaussian's 64-byte row.
+    {
+      bool nz = false;
+      if (tid < bsize) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) nz = nz || (sb.acc[tid * AP + k] != 0.f);
+      }
+      unsigned long long mask = __ballot(nz);
+      int cnt = __popcll(mask);
+      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+      __syncthreads();
+      int f = lane & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        int gi = i0 + (lane >> 4);
+        if (gi < cnt && f < A) {
+          int sl = sb.list[wv][gi];
+          size_t g = (size_t)sb.id[sl];
+          atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward 2: per-Gaussian vjp of projection + colour, and the pose reduction.
+// Reads (and clears) the 64-byte gradient rows.  partial rows: [v_R 9][v_t 3][v_campos 3].
+// ------------------------------------------------------------------------------------------------
+template <bool FULL, int D>
+__global__ __launch_bounds__(256) void k_fproject_bwd(
+    const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
+    const float* __restrict__ opacities, const float* __restrict__ colors, int sh_degree, int K_sh,
+    const float* __restrict__ V, const float* __restrict__ Kmat, int N, int W, int H, float eps2d, int antialiased,
+    const int32_t* __restrict__ radii, const float4* __restrict__ Q1, const float* __restrict__ comps,
+    float4* __restrict__ vacc, float* __restrict__ v_means, float* __restrict__ v_quats,
+    float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
+    float* __restrict__ partials) {
+  constexpr bool RGB = D >= 3;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  Cam cam = load_cam(V, Kmat);
+  float acc15[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) acc15[k] = 0.f;
+  float vmean[3] = {0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f}, vs[3] = {0.f, 0.f, 0.f};
+  float vop = 0.f;
+  float vrgb[3] = {0.f, 0.f, 0.f};
+  bool live = (i < N) && (radii[i] > 0);
+  bool sh_live = false;
+  if (live) {
+    float4 r0 = vacc[4 * (size_t)i], r1 = vacc[4 * (size_t)i + 1], r2 = vacc[4 * (size_t)i + 2];
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    vacc[4 * (size_t)i] = z; vacc[4 * (size_t)i + 1] = z; vacc[4 * (size_t)i + 2] = z;
+    // row = [vx vy | va vb vc | vop | col0 col1 col2 col3 ...]
+    float vm2x = r0.x, vm2y = r0.y, v_ca = r0.z, v_cb = r0.w, v_cc = r1.x, vop_eff = r1.y;
+    float col[4] = {r1.z, r1.w, r2.x, r2.y};
+    float vdepth = (D == 1) ? col[0] : ((D == 4) ? col[3] : 0.f);
+    if (RGB) { vrgb[0] = col[0]; vrgb[1] = col[1]; vrgb[2] = col[2]; }
+    float comp = 0.f, vcomp = 0.f;
+    vop = vop_eff;
+    if (antialiased) {
+      comp = comps[i];
+      vcomp = vop_eff * opacities[i];
+      vop = vop_eff * comp;
+    }
+    ProjMid p;
+    float q[4], s[3];
+    load_gaussian(means, quats, scales, i, cam, p, q, s);
+    p.covar = quat_scale_to_covar(q, s);
+    p.covar_c = mul_bt(mul(cam.R, p.covar), cam.R);
+    persp_mid(cam, W, H, p);
+    float4 q1 = Q1[i];
+    project_vjp<FULL>(cam, eps2d, p, q, s, q1.x, q1.y, q1.z, vm2x, vm2y, vdepth, v_ca, v_cb, v_cc, antialiased != 0,
+                      comp, vcomp, acc15, vmean, vq, vs);
+    sh_live = RGB && (sh_degree >= 0) && (vrgb[0] != 0.f || vrgb[1] != 0.f || vrgb[2] != 0.f);
+    if (sh_live) {
+      // colour = max(SH(dir) + 0.5, 0), dir = mean - campos
+      M3 Ri;
+      float cp[3];
+      cam_inverse(cam, Ri, cp);
+      float rx = p.mean[0] - cp[0], ry = p.mean[1] - cp[1], rz = p.mean[2] - cp[2];
+      float inorm = rsqrtf(rx * rx + ry * ry + rz * rz);
+      float x = rx * inorm, y = ry * inorm, zz = rz * inorm;
+      float Y[16];
+      sh_basis(sh_degree, x, y, zz, Y);
+      int nK = (sh_degree + 1) * (sh_degree + 1);
+      const float* cf = colors + (size_t)i * K_sh * 3;
+      float c0 = 0.5f, c1 = 0.5f, c2 = 0.5f;
+      for (int k = 0; k < nK; ++k) {
+        c0 += Y[k] * cf[3 * k]; c1 += Y[k] * cf[3 * k + 1]; c2 += Y[k] * cf[3 * k + 2];
+      }
+      if (!(c0 > 0.f)) vrgb[0] = 0.f;  // clamp_min(x, 0) passes the gradient where x > 0
+      if (!(c1 > 0.f)) vrgb[1] = 0.f;
+      if (!(c2 > 0.f)) vrgb[2] = 0.f;
+      float sk[16];
+      for (int k = 0; k < nK; ++k) {
+        sk[k] = cf[3 * k] * vrgb[0] + cf[3 * k + 1] * vrgb[1] + cf[3 * k + 2] * vrgb[2];
+        if (FULL) {
+          v_colors[((size_t)i * K_sh + k) * 3] = Y[k] * vrgb[0];
+          v_colors[((size_t)i * K_sh + k) * 3 + 1] = Y[k] * vrgb[1];
+          v_colors[((size_t)i * K_sh + k) * 3 + 2] = Y[k] * vrgb[2];
+        }
+      }
+      if (FULL)
+        for (int k = nK * 3; k < K_sh * 3; ++k) v_colors[(size_t)i * K_sh * 3 + k] = 0.f;
+      float g[3];
+      sh_basis_grad(sh_degree, x, y, zz, sk, g);
+      float dd = g[0] * x + g[1] * y + g[2] * zz;
+      float gd[3] = {(g[0] - dd * x) * inorm, (g[1] - dd * y) * inorm, (g[2] - dd * zz) * inorm};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        vmean[k] += gd[k];
+        acc15[12 + k] = -gd[k];
+      }
+    }
+  }
+  if (FULL && i < N) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_means[3 * (size_t)i + k] = vmean[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v_quats[4 * (size_t)i + k] = vq[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_scales[3 * (size_t)i + k] = vs[k];
+    v_opacities[i] = vop;
+    if (RGB && !sh_live) {
+      if (sh_degree < 0) {
+        v_colors[3 * (size_t)i] = vrgb[0]; v_colors[3 * (size_t)i + 1] = vrgb[1]; v_colors[3 * (size_t)i + 2] = vrgb[2];
+      } else {
+        for (int k = 0; k < K_sh * 3; ++k) v_colors[(size_t)i * K_sh * 3 + k] = 0.f;
+      }
+    }
+  }
+  if (partials != nullptr) {
+    __shared__ float red[4][15];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+      float sum = wave_sum(acc15[k]);
+      if (lane == 0) red[wv][k] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 15)
+      partials[(size_t)blockIdx.x * 16 + threadIdx.x] =
+          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+// Fixed-order sum of the partial rows, chain of the SH view direction through the camera
+// position (campos = -R^-1 t), result into v_viewmat[16] (row 3 = 0: that row is constant).
+__global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict__ partials, int nb,
+                                                        const float* __restrict__ V, const float* __restrict__ Kmat,
+                                                        float* __restrict__ v_viewmat) {
+  __shared__ float red[4][15];
+  __shared__ float tot[15];
+  float acc[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) acc[k] = 0.f;
+  for (int b = threadIdx.x; b < nb; b += 256)
+#pragma unroll
+    for (int k = 0; k < 15; ++k) acc[k] += partials[(size_t)b * 16 + k];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    float s = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    float v = 0.f;
+    if (r < 3) {
+      Cam cam = load_cam(V, Kmat);
+      M3 Ri;
+      float cp[3];
+      cam_inverse(cam, Ri, cp);
+      // w = R^-T v_campos
+      float w = Ri(0, r) * tot[12] + Ri(1, r) * tot[13] + Ri(2, r) * tot[14];
+      if (c < 3) v = tot[r * 3 + c] - w * cp[c];
+      else v = tot[9 + r] - w;
+    }
+    v_viewmat[threadIdx.x] = v;
+  }
+}
+
+}  // namespace gsl
+
+// ---------------------------------------------------------------------------------------------- C ABI
+extern "C" size_t gsl_fused_ws_bytes(int N, int n_tiles) {
+  // [tile_counts n_tiles][cursors n_tiles][partials ceil(N/256)*16 floats]
+  size_t nb = ((size_t)(N > 0 ? N : 1) + 255) / 256;
+  return (size_t)2 * (size_t)(n_tiles > 0 ? n_tiles : 1) * sizeof(int32_t) + nb * 16 * sizeof(float);
+}
+
+extern "C" int gsl_fused_project(const float* means, const float* quats, const float* scales, const float* opacities,
+                                 const float* colors, int sh_degree, int K_sh, const float* viewmat, const float* K,
+                                 int N, int width, int height, float eps2d, float near_plane, float far_plane,
+                                 float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
+                                 int32_t* radii, float* Q0, float* Q1, float* Q2, float* compensations,
+                                 int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (N < 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
+  if (nst > GSL_F_MAX_STRIP_TILES) return GSL_ERR_BAD_ARG;
+  if (!viewmat || !K || !tile_offsets || !n_isects) return GSL_ERR_BAD_ARG;
+  if (N > 0 && (!means || !quats || !scales || !opacities || !radii || !Q0 || !Q1)) return GSL_ERR_BAD_ARG;
+  if (Q2 && !colors) return GSL_ERR_BAD_ARG;
+  if (Q2 && sh_degree >= 0 && (sh_degree > 3 || K_sh < (sh_degree + 1) * (sh_degree + 1))) return GSL_ERR_BAD_ARG;
+  if (antialiased && !compensations) return GSL_ERR_BAD_ARG;
+  if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* counts = (int32_t*)ws;
+  int32_t* cursors = counts + n_tiles;
+  if (hipMemsetAsync(counts, 0, (size_t)n_tiles * sizeof(int32_t), st) != hipSuccess) return GSL_ERR_HIP;
+  if (N > 0) {
+    dim3 grid((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), block(GSL_F_BIN_THREADS);
+    size_t lds = (size_t)(nst > 0 ? nst : 1) * sizeof(int);
+    if (Q2)
+      hipLaunchKernelGGL(gsl::k_fproject<true>, grid, block, lds, st, means, quats, scales, opacities, colors,
+                         sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,
+                         antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,
+                         compensations, tiles_per_gauss, counts);
+    else
+      hipLaunchKernelGGL(gsl::k_fproject<false>, grid, block, lds, st, means, quats, scales, opacities, colors,
+                         sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,
+                         antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,
+                         compensations, tiles_per_gauss, counts);
+    GSL_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(gsl::k_ftile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+// defined in binning.hip
+extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+                             uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
+                             void* stream);
+
+extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0, int ty1,
+                             int tile_n_bits, const int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
+                             int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes, void* stream) {
+  if (N < 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
+  if (nst > GSL_F_MAX_STRIP_TILES || !tile_offsets) return GSL_ERR_BAD_ARG;
+  if (N == 0 || capacity == 0 || nst == 0) return GSL_OK;
+  if (!Q0 || !radii || !sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
+  if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* cursors = (int32_t*)ws + n_tiles;
+  hipLaunchKernelGGL(gsl::k_fscatter, dim3((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), dim3(GSL_F_BIN_THREADS),
+                     (size_t)2 * nst * sizeof(int), st, (const float4*)Q0, radii, N, tile_w, tile_h, ty0, ty1,
+                     tile_offsets, cursors, (long long)capacity, sort_keys);
+  GSL_CHECK_LAUNCH();
+  return gsl_tile_sort(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0, stream);
+}
+
+#define GSL_F_DISPATCH(D, ED, CALL)                     \
+  if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
+  else if (D == 3) { CALL(3, false); }                          \
+  else if (D == 4) { if (ED) CALL(4, true); else CALL(4, false); } \
+  else return GSL_ERR_BAD_ARG;
+
+extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                                    int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                                    float* render, float* alphas, int32_t* last_ids, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids) return GSL_ERR_BAD_ARG;
+  if (capacity > 0 && (!Q0 || !Q1 || !flatten_ids)) return GSL_ERR_BAD_ARG;
+  if (channels >= 3 && capacity > 0 && !Q2) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (ty0 == ty1) return GSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (ty1 - ty0) * tile_w;
+#define CALL_FF(DD, EE)                                                                                       \
+  hipLaunchKernelGGL((gsl::k_fraster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids)
+  GSL_F_DISPATCH(channels, ed, CALL_FF)
+#undef CALL_FF
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                                    int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                                    const float* render, const float* alphas, const int32_t* last_ids,
+                                    const float* v_render, const float* v_alphas, float* vacc, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (capacity == 0 || ty0 == ty1) return GSL_OK;
+  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (ty1 - ty0) * tile_w;
+#define CALL_FB(DD, EE)                                                                                       \
+  hipLaunchKernelGGL((gsl::k_fraster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
+  GSL_F_DISPATCH(channels, ed, CALL_FB)
+#undef CALL_FB
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
+                                     const float* opacities, const float* colors, int sh_degree, int K_sh,
+                                     const float* viewmat, const float* K, int N, int width, int height,
+                                     float eps2d, int antialiased, int channels, const int32_t* radii,
+                                     const float* Q1, const float* compensations, float* vacc, float* v_means,
+                                     float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
+                                     float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream) {
+  if (N < 0 || width <= 0 || height <= 0 || n_tiles <= 0) return GSL_ERR_BAD_ARG;
+  if (channels != 1 && channels != 3 && channels != 4) return GSL_ERR_BAD_ARG;
+  bool full = v_means != nullptr;
+  if (full != (v_quats != nullptr) || full != (v_scales != nullptr) || full != (v_opacities != nullptr))
+    return GSL_ERR_BAD_ARG;
+  if (full && channels >= 3 && !v_colors) return GSL_ERR_BAD_ARG;
+  if (antialiased && !compensations) return GSL_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) {
+    if (v_viewmat && hipMemsetAsync(v_viewmat, 0, 16 * sizeof(float), st) != hipSuccess) return GSL_ERR_HIP;
+    return GSL_OK;
+  }
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !Q1 || !vacc) return GSL_ERR_BAD_ARG;
+  if (channels >= 3 && !colors) return GSL_ERR_BAD_ARG;
+  if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
+  float* partials = v_viewmat ? (float*)((int32_t*)ws + 2 * (size_t)n_tiles) : nullptr;
+  int grid = (N + 255) / 256;
+#define CALL_PB(FF, DD)                                                                                          \
+  hipLaunchKernelGGL((gsl::k_fproject_bwd<FF, DD>), dim3(grid), dim3(256), 0, st, means, quats, scales, opacities, \
+                     colors, sh_degree, K_sh, viewmat, K, N, width, height, eps2d, antialiased, radii,             \
+                     (const float4*)Q1, compensations, (float4*)vacc, v_means, v_quats, v_scales, v_opacities,    \
+                     v_colors, partials)
+  if (full) {
+    if (channels == 1) CALL_PB(true, 1); else if (channels == 3) CALL_PB(true, 3); else CALL_PB(true, 4);
+  } else {
+    if (channels == 1) CALL_PB(false, 1); else if (channels == 3) CALL_PB(false, 3); else CALL_PB(false, 4);
+  }
+#undef CALL_PB
+  GSL_CHECK_LAUNCH();
+  if (v_viewmat) {
+    hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
+    GSL_CHECK_LAUNCH();
+  }
+  return GSL_OK;
+}

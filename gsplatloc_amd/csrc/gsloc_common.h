@@ -92,11 +92,23 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
   return c;
 }
 
-// 64-lane butterfly sum (DPP/ds_swizzle under the hood); every lane gets the total.
+// DPP lane exchange (no LDS traffic).  Lanes a row_mask disables contribute 0.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
+}
+
+// Sum over the 64 lanes of a wave in 6 DPP adds (quad swaps, row mirrors, row broadcasts);
+// the total comes back wave-uniform (scalar register) from lane 63.  Fixed order => deterministic.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_get<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_get<0x141>(v);       // row_half_mirror
+  v += dpp_get<0x140>(v);       // row_mirror: every lane holds its 16-lane row sum
+  v += dpp_get<0x142, 0xA>(v);  // row_bcast15 into rows 1,3
+  v += dpp_get<0x143, 0xC>(v);  // row_bcast31 into rows 2,3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Tile rectangle of a projected Gaussian: [xmin,xmax) x [ymin,ymax) in tiles.

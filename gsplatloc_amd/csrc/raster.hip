@@ -128,16 +128,21 @@ __global__ __launch_bounds__(256) void k_raster_fwd(
   }
 }
 
+// Per-Gaussian gradient accumulator row ("vacc"): [v_xy 2][v_conic 3][v_opacity 1][v_color D], padded
+// to 16 floats (64 B, one cache line / one atomic request) for D <= 10, 48 floats otherwise.
+__host__ __device__ constexpr int vacc_stride(int D) { return (6 + D <= 16) ? 16 : 48; }
+
 template <int D>
 struct BatchB {
+  static constexpr int A = 6 + D;
+  static constexpr int AP = A | 1;                  // odd row pitch: conflict-free LDS access
+  static constexpr int NACC = (D <= 5) ? 4 : 1;     // one accumulator per wave while LDS allows
   float x[256], y[256], ca[256], cb[256], cc[256], op[256];
   float hx[256], hy[256];
   int32_t id[256];
   float col[256 * D];
-  // gradient accumulators v_xy(2) v_conic(3) v_op(1) v_col(D): one per wave (deterministic
-  // fixed-order sum) while they fit in LDS, one shared (LDS float atomics) for wide colours
-  static constexpr int NACC = (D <= 5) ? 4 : 1;
-  float acc[NACC][256 * (6 + D)];
+  float acc[NACC][256 * AP];
+  uint16_t list[4][64];
 };
 
 template <int D>
@@ -147,10 +152,11 @@ __global__ __launch_bounds__(256) void k_raster_bwd(
     const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids, long long capacity,
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
-    float* __restrict__ v_means2d, float* __restrict__ v_conics, float* __restrict__ v_colors,
-    float* __restrict__ v_opacities) {
-  constexpr int A = 6 + D;
+    float* __restrict__ vacc) {
+  constexpr int A = BatchB<D>::A;
+  constexpr int AP = BatchB<D>::AP;
   constexpr int NACC = BatchB<D>::NACC;
+  constexpr int AS = vacc_stride(D);
   __shared__ BatchB<D> sb;
   int tile = ty0 * tile_w + blockIdx.x;
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
@@ -164,7 +170,6 @@ __global__ __launch_bounds__(256) void k_raster_bwd(
   long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
   if (re > capacity) re = capacity;
   if (rs >= re) return;
-  int nb = (int)((re - rs + 255) / 256);
 
   size_t pid = inside ? ((size_t)i * W + j) : 0;
   float T_final = inside ? (1.f - render_alphas[pid]) : 1.f;
@@ -179,10 +184,18 @@ __global__ __launch_bounds__(256) void k_raster_bwd(
     buf[k] = 0.f;
     if (backgrounds) bg_dot += backgrounds[k] * vc[k];
   }
-  // the last splat any pixel of the tile composited bounds the work of the whole block
+  // the deepest splat any pixel of the quadrant / tile composited bounds the work
   int wave_final = bin_final;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
+  __shared__ int s_block_final[4];
+  if (lane == 0) s_block_final[wv] = wave_final;
+  __syncthreads();
+  int block_final = max(max(s_block_final[0], s_block_final[1]), max(s_block_final[2], s_block_final[3]));
+  // nothing behind block_final was composited by any pixel: start there
+  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (rs >= re) return;
+  int nb = (int)((re - rs + 255) / 256);
 
   for (int b = 0; b < nb; ++b) {
     // batch b covers absolute indices [bend-bsize+1, bend], staged back to front: slot t <-> bend - t
@@ -205,9 +218,8 @@ __global__ __launch_bounds__(256) void k_raster_bwd(
 #pragma unroll
     for (int w = 0; w < NACC; ++w)
 #pragma unroll
-      for (int k = 0; k < A; ++k) sb.acc[w][k * 256 + tid] = 0.f;
+      for (int k = 0; k < A; ++k) sb.acc[w][tid * AP + k] = 0.f;
     __syncthreads();
-    // slots whose absolute index exceeds every lane's last composited splat need no work
     int t_first = (int)max((long long)0, bend - (long long)wave_final);
     for (int c = (t_first / 64) * 64; c < bsize; c += 64) {
       int e = c + lane;
@@ -266,48 +278,70 @@ __global__ __launch_bounds__(256) void k_raster_bwd(
         for (int k = 0; k < D; ++k) g_col[k] = wave_sum(g_col[k]);
         if (lane == 0) {
           if (NACC == 4) {
-            float* a = sb.acc[wv];
-            a[0 * 256 + t] = g_xy0; a[1 * 256 + t] = g_xy1;
-            a[2 * 256 + t] = g_c0; a[3 * 256 + t] = g_c1; a[4 * 256 + t] = g_c2;
-            a[5 * 256 + t] = g_op;
+            float* a = sb.acc[wv] + t * AP;
+            a[0] = g_xy0; a[1] = g_xy1; a[2] = g_c0; a[3] = g_c1; a[4] = g_c2; a[5] = g_op;
 #pragma unroll
-            for (int k = 0; k < D; ++k) a[(6 + k) * 256 + t] = g_col[k];
+            for (int k = 0; k < D; ++k) a[6 + k] = g_col[k];
           } else {
-            float* a = sb.acc[0];
-            atomicAdd(&a[0 * 256 + t], g_xy0); atomicAdd(&a[1 * 256 + t], g_xy1);
-            atomicAdd(&a[2 * 256 + t], g_c0); atomicAdd(&a[3 * 256 + t], g_c1); atomicAdd(&a[4 * 256 + t], g_c2);
-            atomicAdd(&a[5 * 256 + t], g_op);
+            float* a = sb.acc[0] + t * AP;
+            atomicAdd(&a[0], g_xy0); atomicAdd(&a[1], g_xy1);
+            atomicAdd(&a[2], g_c0); atomicAdd(&a[3], g_c1); atomicAdd(&a[4], g_c2);
+            atomicAdd(&a[5], g_op);
 #pragma unroll
-            for (int k = 0; k < D; ++k) atomicAdd(&a[(6 + k) * 256 + t], g_col[k]);
+            for (int k = 0; k < D; ++k) atomicAdd(&a[6 + k], g_col[k]);
           }
         }
       }
     }
     __syncthreads();
-    // flush: thread t owns slot t; fixed wave order keeps the per-tile sum deterministic
-    if (tid < bsize) {
-      float s[A];
+    // Flush.  Thread t folds the per-wave partials of slot t in a fixed order (deterministic per
+    // tile), then each wave packs its non-zero slots so that 16 consecutive lanes add one
+    // Gaussian's 64-byte accumulator row: one atomic request per (tile, splat) pair.
+    {
       bool nz = false;
+      if (tid < bsize) {
 #pragma unroll
-      for (int k = 0; k < A; ++k) {
-        s[k] = sb.acc[0][k * 256 + tid];
+        for (int k = 0; k < A; ++k) {
+          float v = sb.acc[0][tid * AP + k];
 #pragma unroll
-        for (int w = 1; w < NACC; ++w) s[k] += sb.acc[w][k * 256 + tid];
-        nz = nz || (s[k] != 0.f);
+          for (int w = 1; w < NACC; ++w) v += sb.acc[w][tid * AP + k];
+          if (NACC > 1) sb.acc[0][tid * AP + k] = v;
+          nz = nz || (v != 0.f);
+        }
       }
-      if (nz) {
-        size_t g = (size_t)sb.id[tid];
-        atomicAdd(&v_means2d[2 * g], s[0]);
-        atomicAdd(&v_means2d[2 * g + 1], s[1]);
-        atomicAdd(&v_conics[3 * g], s[2]);
-        atomicAdd(&v_conics[3 * g + 1], s[3]);
-        atomicAdd(&v_conics[3 * g + 2], s[4]);
-        atomicAdd(&v_opacities[g], s[5]);
-#pragma unroll
-        for (int k = 0; k < D; ++k) atomicAdd(&v_colors[g * D + k], s[6 + k]);
+      unsigned long long mask = __ballot(nz);
+      int cnt = __popcll(mask);
+      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+      __syncthreads();
+      constexpr int LPG = (A <= 16) ? 16 : 64;  // lanes per accumulator row
+      constexpr int GPW = 64 / LPG;
+      int f = lane % LPG;
+      for (int i0 = 0; i0 < cnt; i0 += GPW) {
+        int gi = i0 + lane / LPG;
+        if (gi < cnt && f < A) {
+          int sl = sb.list[wv][gi];
+          size_t g = (size_t)sb.id[sl];
+          atomicAdd(&vacc[g * AS + f], sb.acc[0][sl * AP + f]);
+        }
       }
     }
   }
+}
+
+// vacc rows -> the four gsplat-style gradient tensors.
+__global__ __launch_bounds__(256) void k_vacc_unpack(const float* __restrict__ vacc, int n, int D, int AS,
+                                                     float* __restrict__ v_means2d, float* __restrict__ v_conics,
+                                                     float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* r = vacc + (size_t)i * AS;
+  v_means2d[2 * (size_t)i] = r[0];
+  v_means2d[2 * (size_t)i + 1] = r[1];
+  v_conics[3 * (size_t)i] = r[2];
+  v_conics[3 * (size_t)i + 1] = r[3];
+  v_conics[3 * (size_t)i + 2] = r[4];
+  v_opacities[i] = r[5];
+  for (int k = 0; k < D; ++k) v_colors[(size_t)i * D + k] = r[6 + k];
 }
 
 template <int D>
@@ -327,12 +361,11 @@ static int launch_bwd(const float* means2d, const float* conics, const float* co
                       const float* backgrounds, int W, int H, int tile_w, int ty0, int ty1,
                       const int32_t* tile_offsets, const int32_t* flatten_ids, long long capacity,
                       const float* render_alphas, const int32_t* last_ids, const float* v_render_colors,
-                      const float* v_render_alphas, float* v_means2d, float* v_conics, float* v_colors,
-                      float* v_opacities, hipStream_t st) {
+                      const float* v_render_alphas, float* vacc, hipStream_t st) {
   int nblk = (ty1 - ty0) * tile_w;
   hipLaunchKernelGGL(k_raster_bwd<D>, dim3(nblk), dim3(256), 0, st, means2d, conics, colors, opacities, backgrounds,
                      W, H, tile_w, ty0, tile_offsets, flatten_ids, capacity, render_alphas, last_ids,
-                     v_render_colors, v_render_alphas, v_means2d, v_conics, v_colors, v_opacities);
+                     v_render_colors, v_render_alphas, vacc);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -373,13 +406,17 @@ extern "C" int gsl_rasterize_fwd(const float* means2d, const float* conics, cons
 #undef CALL_FWD
 }
 
+extern "C" size_t gsl_vacc_bytes(int n_gaussians, int channels) {
+  return (size_t)(n_gaussians > 0 ? n_gaussians : 0) * gsl::vacc_stride(channels) * sizeof(float);
+}
+
 extern "C" int gsl_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
                                  const float* opacities, const float* backgrounds, int channels, int width,
                                  int height, int tile_size, int tile_w, int tile_h, int ty0, int ty1,
                                  const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                  const float* render_alphas, const int32_t* last_ids,
-                                 const float* v_render_colors, const float* v_render_alphas, float* v_means2d,
-                                 float* v_conics, float* v_colors, float* v_opacities, void* stream) {
+                                 const float* v_render_colors, const float* v_render_alphas, float* vacc,
+                                 void* stream) {
   if (tile_size != 16) return GSL_ERR_BAD_ARG;
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0)
@@ -387,14 +424,23 @@ extern "C" int gsl_rasterize_bwd(const float* means2d, const float* conics, cons
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
   if (!tile_offsets || !render_alphas || !last_ids || !v_render_colors || !v_render_alphas) return GSL_ERR_BAD_ARG;
   if (capacity == 0 || ty0 == ty1) return GSL_OK;
-  if (!means2d || !conics || !colors || !opacities || !flatten_ids || !v_means2d || !v_conics || !v_colors ||
-      !v_opacities)
-    return GSL_ERR_BAD_ARG;
+  if (!means2d || !conics || !colors || !opacities || !flatten_ids || !vacc) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
 #define CALL_BWD(DD)                                                                                             \
   gsl::launch_bwd<DD>(means2d, conics, colors, opacities, backgrounds, width, height, tile_w, ty0, ty1,         \
                       tile_offsets, flatten_ids, (long long)capacity, render_alphas, last_ids, v_render_colors,  \
-                      v_render_alphas, v_means2d, v_conics, v_colors, v_opacities, st)
+                      v_render_alphas, vacc, st)
   GSL_DISPATCH_D(channels, CALL_BWD)
 #undef CALL_BWD
+}
+
+extern "C" int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_means2d, float* v_conics,
+                               float* v_colors, float* v_opacities, void* stream) {
+  if (n_gaussians < 0 || channels <= 0 || channels > 32) return GSL_ERR_BAD_ARG;
+  if (n_gaussians == 0) return GSL_OK;
+  if (!vacc || !v_means2d || !v_conics || !v_colors || !v_opacities) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_vacc_unpack, dim3((n_gaussians + 255) / 256), dim3(256), 0, (hipStream_t)stream, vacc,
+                     n_gaussians, channels, gsl::vacc_stride(channels), v_means2d, v_conics, v_colors, v_opacities);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
 }

@@ -326,19 +326,21 @@ class _RasterizeToPixels(torch.autograd.Function):
         n_isects = flatten_ids.numel()
         v_render_colors = v_render_colors.contiguous()
         v_render_alphas = v_render_alphas.contiguous()
-        v_means2d = torch.zeros_like(means2d)
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opacities = torch.zeros_like(opacities)
+        v_means2d = torch.empty_like(means2d)
+        v_conics = torch.empty_like(conics)
+        v_colors = torch.empty_like(colors)
+        v_opacities = torch.empty_like(opacities)
         st = current_stream()
+        vacc = torch.zeros(lib.gsl_vacc_bytes(C * N, D) // 4, dtype=torch.float32, device=means2d.device)
         if n_isects:
             for c in range(C):
                 check(lib.gsl_rasterize_bwd(
                     ptr(means2d), ptr(conics), ptr(colors), ptr(opacities), ptr(backgrounds[c]) if has_bg else None,
                     D, width, height, tile_size, tw, th, 0, th, ptr(offs_ext[c * n_tiles:]), ptr(flatten_ids),
                     n_isects, ptr(render_alphas[c]), ptr(last_ids[c]), ptr(v_render_colors[c]),
-                    ptr(v_render_alphas[c]), ptr(v_means2d), ptr(v_conics), ptr(v_colors), ptr(v_opacities), st),
-                    "gsl_rasterize_bwd")
+                    ptr(v_render_alphas[c]), ptr(vacc), st), "gsl_rasterize_bwd")
+        check(lib.gsl_vacc_unpack(ptr(vacc), C * N, D, ptr(v_means2d), ptr(v_conics), ptr(v_colors),
+                                  ptr(v_opacities), st), "gsl_vacc_unpack")
         v_backgrounds = None
         if has_bg and ctx.needs_input_grad[4]:
             v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))

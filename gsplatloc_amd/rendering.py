@@ -15,6 +15,9 @@ import torch
 from torch import Tensor
 from typing_extensions import Literal
 
+import os
+
+from .fused import fused_rasterization, fused_supported
 from .ops import (
     fully_fused_projection,
     isect_offset_encode,
@@ -93,6 +96,16 @@ def rasterization(
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
 
+    # Hot path: one camera, no background -> the fused five-launch pipeline (csrc/fused.hip).
+    if os.environ.get("GSLOC_DISABLE_FUSED", "0") != "1" and fused_supported(
+            N, C, colors, sh_degree, width, height, tile_size, backgrounds, render_mode):
+        render, alphas, meta = fused_rasterization(
+            means, quats, scales, opacities, colors, viewmats[0], Ks[0], width, height, sh_degree=sh_degree,
+            render_mode=render_mode, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
+            radius_clip=radius_clip, antialiased=(rasterize_mode == "antialiased"))
+        return render[None], alphas[None], meta
+
+    # General path (several cameras, backgrounds, wide colour channels): stage operators.
     # Project Gaussians to 2D.
     radii, means2d, depths, conics, compensations = fully_fused_projection(
         means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,

@@ -1,0 +1,56 @@
+"""Seeded synthetic workloads: no dataset is needed or read.
+
+* ``random_scene``   -- "Random-N": u,v uniform over the image, z ~ U(1,5) m, isotropic
+  scale s = sigma_px * z / fx, identity quaternions, opacity 1 (as GSModel builds them,
+  /root/reference/src/my_gsplat/model.py:156-165), SH degree 1 with a random DC term.
+* ``replica_intrinsics`` -- /root/reference/datasets/Replica/cam_params.json:3-9.
+* ``perturbed_pose`` -- GT = identity, initial pose = GT rotated by ``rot_deg`` about a seeded
+  axis and shifted by ``trans`` metres.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+SH_C0 = 0.28209479177387814
+
+
+def replica_intrinsics(W: int = 1200, H: int = 680, dtype=torch.float32) -> torch.Tensor:
+    fx = 600.0 * W / 1200.0
+    fy = 600.0 * H / 680.0
+    return torch.tensor([[fx, 0.0, (W - 1) / 2.0], [0.0, fy, (H - 1) / 2.0], [0.0, 0.0, 1.0]], dtype=dtype)
+
+
+def random_scene(N: int, W: int, H: int, seed: int = 42, sigma_px: float = 1.0, device="cpu") -> Dict:
+    g = torch.Generator().manual_seed(seed)
+    K = replica_intrinsics(W, H)
+    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+    u = torch.rand(N, generator=g) * W
+    v = torch.rand(N, generator=g) * H
+    z = 1.0 + 4.0 * torch.rand(N, generator=g)
+    means = torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1)
+    quats = torch.tensor([1.0, 0.0, 0.0, 0.0]).repeat(N, 1)
+    scales = (max(sigma_px, 1e-4) * z / fx)[:, None].repeat(1, 3)
+    opacities = torch.ones(N)
+    rgbs = torch.rand(N, 3, generator=g)
+    sh = torch.zeros(N, 4, 3)
+    sh[:, 0, :] = (rgbs - 0.5) / SH_C0
+    out = dict(means=means, quats=quats, scales=scales, opacities=opacities, sh=sh, rgbs=rgbs, K=K, W=W, H=H, N=N)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+def perturbed_pose(rot_deg: float = 0.5, trans: float = 0.01, seed: int = 7) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    ax = torch.randn(3, generator=g, dtype=torch.float64)
+    ax = ax / ax.norm()
+    th = math.radians(rot_deg)
+    Kx = torch.tensor([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]], dtype=torch.float64)
+    R = torch.eye(3, dtype=torch.float64) + math.sin(th) * Kx + (1 - math.cos(th)) * (Kx @ Kx)
+    d = torch.randn(3, generator=g, dtype=torch.float64)
+    d = d / d.norm() * trans
+    c2w = torch.eye(4, dtype=torch.float64)
+    c2w[:3, :3] = R
+    c2w[:3, 3] = d
+    return c2w.float()

@@ -97,6 +97,12 @@ int gsl_isect_fill(const float* means2d, const int32_t* radii, const float* dept
                    uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
                    size_t ws_bytes, void* stream);
 
+/* Sort every tile bucket of tiles [tile_begin, tile_begin+n_strip_tiles) on (depth bits, id) and
+ * write flatten_ids / isect_ids (second half of gsl_isect_fill; cam_enc is OR-ed into isect_ids). */
+int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+                  uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
+                  void* stream);
+
 /* Unsorted emit in Gaussian order (isect_tiles(sort=False)): cum_tiles[N] is the
  * INCLUSIVE cumulative sum of tiles_per_gauss (int64). */
 int gsl_isect_emit(const float* means2d, const int32_t* radii, const float* depths,
@@ -119,14 +125,67 @@ int gsl_rasterize_fwd(const float* means2d, const float* conics, const float* co
                       const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                       float* render_colors, float* render_alphas, int32_t* last_ids, void* stream);
 
-/* vjp.  v_* per-Gaussian outputs are ACCUMULATED INTO (caller zeroes them). */
+/* vjp.  Per-Gaussian gradients are ACCUMULATED INTO `vacc`, one padded row per Gaussian:
+ * [v_means2d 2][v_conics 3][v_opacity 1][v_colors channels], row pitch 16 floats for
+ * channels <= 10 and 48 floats otherwise (gsl_vacc_bytes gives the size).  The caller zeroes
+ * vacc before the first camera; rows are indexed by the same ids as flatten_ids.
+ * gsl_vacc_unpack splits the rows into the four gsplat gradient tensors. */
+size_t gsl_vacc_bytes(int n_gaussians, int channels);
 int gsl_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
                       const float* opacities, const float* backgrounds, int channels, int width,
                       int height, int tile_size, int tile_w, int tile_h, int ty0, int ty1,
                       const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                       const float* render_alphas, const int32_t* last_ids,
-                      const float* v_render_colors, const float* v_render_alphas, float* v_means2d,
-                      float* v_conics, float* v_colors, float* v_opacities, void* stream);
+                      const float* v_render_colors, const float* v_render_alphas, float* vacc,
+                      void* stream);
+int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_means2d,
+                    float* v_conics, float* v_colors, float* v_opacities, void* stream);
+
+/* ---- fused single-camera pipeline: gsplat.rasterization end to end (IDX:14954) ----
+ * The hot path of GsplatLoc's tracker (model.py:195-213).  16x16 tiles.  Per-Gaussian state lives
+ * in 16-byte records: Q0[N] = (x, y, depth, opacity_eff), Q1[N] = (conic a, b, c, r_cull),
+ * Q2[N] = (r, g, b, 0) (NULL for depth-only rendering).  channels: 1 = depth, 3 = RGB,
+ * 4 = RGB + depth; ed != 0 divides the depth channel by alpha (render modes "ED"/"RGB+ED").
+ * colors: SH coefficients [N,K_sh,3] when sh_degree in 0..3, direct RGB [N,3] when sh_degree < 0.
+ * ws: gsl_fused_ws_bytes(N, tile_w*tile_h), shared by the five calls of one render.
+ *
+ * gsl_fused_project : projection + colour + pack + tile histogram + scan
+ *                     -> radii, Q0, Q1, Q2, tile_offsets[n_tiles+1], n_isects[1]
+ * gsl_fused_bin     : scatter + per-tile sort -> flatten_ids (isect_ids optional)
+ * gsl_fused_raster_fwd / _bwd : compositing and its vjp; the vjp ACCUMULATES into vacc, 16 floats
+ *                     per Gaussian ([v_xy 2][v_conic 3][v_opacity 1][v_colour channels]), zero on entry
+ * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
+ *                     v_colors, shaped like colors) may be NULL together (pose-only);
+ *                     v_viewmat[16] is overwritten (row 3 = 0). */
+size_t gsl_fused_ws_bytes(int N, int n_tiles);
+int gsl_fused_project(const float* means, const float* quats, const float* scales,
+                      const float* opacities, const float* colors, int sh_degree, int K_sh,
+                      const float* viewmat, const float* K, int N, int width, int height,
+                      float eps2d, float near_plane, float far_plane, float radius_clip,
+                      int antialiased, int tile_w, int tile_h, int ty0, int ty1, int32_t* radii,
+                      float* Q0, float* Q1, float* Q2, float* compensations,
+                      int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
+                      size_t ws_bytes, void* stream);
+int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0,
+                  int ty1, int tile_n_bits, const int32_t* tile_offsets, int64_t capacity,
+                  uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
+                  size_t ws_bytes, void* stream);
+int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                         int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                         const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                         float* render, float* alphas, int32_t* last_ids, void* stream);
+int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                         int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                         const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                         const float* render, const float* alphas, const int32_t* last_ids,
+                         const float* v_render, const float* v_alphas, float* vacc, void* stream);
+int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
+                          const float* opacities, const float* colors, int sh_degree, int K_sh,
+                          const float* viewmat, const float* K, int N, int width, int height,
+                          float eps2d, int antialiased, int channels, const int32_t* radii,
+                          const float* Q1, const float* compensations, float* vacc, float* v_means,
+                          float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
+                          float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
 #ifdef __cplusplus
 }

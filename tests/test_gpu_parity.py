@@ -68,7 +68,8 @@ def test_projection_fwd_bwd(aniso):
     for a, b, nm in ((m2_g, m2_o, "means2d"), (d_g, d_o, "depths"), (c_g, c_o, "conics"), (cp_g, cp_o, "comp")):
         mostly_close(a.cpu()[keep], b[keep], rtol=1e-4, atol=1e-6, what=nm)
     # culled entries are zero-filled
-    assert float(m2_g.cpu()[r_g.cpu() == 0].abs().max()) == 0.0
+    culled = m2_g.cpu()[r_g.cpu() == 0]
+    assert culled.numel() == 0 or float(culled.abs().max()) == 0.0
     gen = torch.Generator().manual_seed(11)
     vm2, vd, vc, vcp = (torch.randn(x.shape, generator=gen) * keep.float().reshape(keep.shape + (1,) * (x.dim() - 2))
                         for x in (m2_o, d_o, c_o, cp_o))
@@ -94,7 +95,8 @@ def test_projection_pose_only_matches_full():
         r, m2, d, c, _ = A.fully_fused_projection(m, None, sc["quats"].to(DEV), sc["scales"].to(DEV), Vg, K, 160, 120)
         ((m2 ** 2).sum() + (d * 0.3).sum() + c.sum()).backward()
         out[full] = Vg.grad.clone()
-    assert torch.equal(out[True], out[False]), "pose-only mode must be bit-identical for v_viewmat"
+    # two template instantiations of one kernel: the compiler may contract FMAs differently
+    assert rel_inf(out[True], out[False]) < 1e-6, "pose-only mode must agree with the full backward"
 
 
 @pytest.mark.parametrize("shape", [(160, 120), (100, 70), (33, 17)])
@@ -236,13 +238,17 @@ def test_spherical_harmonics(deg):
     (out_o * v.double()).sum().backward()
     (out_g * v.to(DEV)).sum().backward()
     mostly_close(cg.grad, co.grad, rtol=1e-4, atol=1e-5, what="v_coeffs")
-    mostly_close(dg.grad, do.grad, rtol=1e-3, atol=1e-4, what="v_dirs")
+    v_dirs_o = do.grad if do.grad is not None else torch.zeros_like(do)  # degree 0 ignores dirs
+    mostly_close(dg.grad, v_dirs_o, rtol=1e-3, atol=1e-4, what="v_dirs")
 
 
+@pytest.mark.parametrize("fused", ["fused", "staged"])
 @pytest.mark.parametrize("mode,sh", [("RGB+ED", 1), ("ED", 1), ("RGB", None), ("D", None), ("RGB+D", 1)])
-def test_rasterization_end_to_end(mode, sh):
-    """The exact keyword call of model.py:195-213 / geometry.py:117-132."""
+def test_rasterization_end_to_end(mode, sh, fused, monkeypatch):
+    """The exact keyword call of model.py:195-213 / geometry.py:117-132, through the fused
+    pipeline and through the stage operators."""
     A = _gpu()
+    monkeypatch.setenv("GSLOC_DISABLE_FUSED", "0" if fused == "fused" else "1")
     W, H, N = 160, 120, 6000
     sc = _scene32(N, W, H, sigma_px=1.2, opacity=(0.4, 1.0))
     c2w = small_pose(0.5, 0.01, dtype=torch.float32)
@@ -268,3 +274,75 @@ def test_rasterization_end_to_end(mode, sh):
     (rc_o * v.double()).sum().backward()
     (rc_g * v.to(DEV)).sum().backward()
     assert rel_inf(Vg.grad[0, :3], Vo.grad[0, :3]) < 2e-3, f"v_viewmat {mode}"
+
+
+@pytest.mark.parametrize("mode,sh_deg,aa", [("RGB+ED", 1, False), ("RGB+ED", 3, False), ("RGB", None, False),
+                                            ("ED", 1, False), ("RGB+D", 2, True), ("D", None, True)])
+def test_fused_full_gradients(mode, sh_deg, aa):
+    """Fused pipeline: every input gradient (means, quats, scales, opacities, colours/SH, viewmat)
+    against float64 autograd of the oracle; the loss touches every output channel and alpha."""
+    A = _gpu()
+    W, H, N = 128, 80, 2500
+    sc = _scene32(N, W, H, sigma_px=1.5, opacity=(0.3, 1.0), aniso=True)
+    gen = torch.Generator().manual_seed(17)
+    if sh_deg is None:
+        colors = sc["rgbs"]
+    else:
+        colors = torch.randn(N, (sh_deg + 1) ** 2, 3, generator=gen) * 0.3
+    V = torch.linalg.inv(small_pose(1.0, 0.03, dtype=torch.float32))[None]
+    kw = dict(sh_degree=sh_deg, width=W, height=H, packed=False, render_mode=mode,
+              rasterize_mode="antialiased" if aa else "classic")
+    names = ("means", "quats", "scales", "opacities")
+    ins_o = [sc[k].double().clone().requires_grad_() for k in names] + [colors.double().clone().requires_grad_(),
+                                                                         V.double().clone().requires_grad_()]
+    rc_o, ra_o, _ = G.rasterization(*ins_o[:5], ins_o[5], sc["K"].double()[None], **kw)
+    ins_g = [sc[k].to(DEV).clone().requires_grad_() for k in names] + [colors.to(DEV).clone().requires_grad_(),
+                                                                       V.to(DEV).clone().requires_grad_()]
+    rc_g, ra_g, meta = A.rasterization(*ins_g[:5], viewmats=ins_g[5], Ks=sc["K"][None].to(DEV), **kw)
+    assert "Q0" not in meta and meta["means2d"].shape == (1, N, 2) and meta["conics"].shape == (1, N, 3)
+    mostly_close(rc_g, rc_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="render")
+    mostly_close(ra_g, ra_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="alpha")
+    v_c = torch.randn(rc_o.shape, generator=gen)
+    v_a = torch.randn(ra_o.shape, generator=gen)
+    ((rc_o * v_c.double()).sum() + (ra_o * v_a.double()).sum()).backward()
+    ((rc_g * v_c.to(DEV)).sum() + (ra_g * v_a.to(DEV)).sum()).backward()
+    assert rel_inf(ins_g[5].grad[0, :3], ins_o[5].grad[0, :3]) < 2e-3, "v_viewmat"
+    for g_t, o_t, nm in zip(ins_g[:5], ins_o[:5], names + ("colors",)):
+        if o_t.grad is None:
+            assert g_t.grad is None or float(g_t.grad.abs().max()) == 0.0, nm
+            continue
+        scale = float(o_t.grad.abs().max())
+        mostly_close(g_t.grad, o_t.grad, rtol=2e-3, atol=5e-4 * scale, max_bad_frac=1e-2, what="v_" + nm)
+        assert rel_inf(g_t.grad.sum(0), o_t.grad.sum(0)) < 1e-2, nm + " (summed)"
+
+
+def test_fused_tile_strip_matches_full_render():
+    """Rendering tile rows [ty0,ty1) only reproduces those rows of the full render bit for bit, and the
+    strips' pose gradients add up to the full one (screen-tile parallelism)."""
+    A = _gpu()
+    from gsplatloc_amd.fused import fused_rasterization
+    W, H, N = 160, 120, 5000
+    sc = _scene32(N, W, H, sigma_px=1.3, opacity=(0.4, 1.0))
+    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+    V0 = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV)
+    args = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")]
+    gen = torch.Generator().manual_seed(8)
+    v = torch.randn(H, W, 4, generator=gen).to(DEV)
+
+    def run(rows):
+        Vg = V0.clone().requires_grad_()
+        r, a, m = fused_rasterization(*args, sh, Vg, sc["K"].to(DEV), W, H, sh_degree=1, render_mode="RGB+ED",
+                                      tile_rows=rows)
+        (r * v).sum().backward()
+        return r.detach(), a.detach(), Vg.grad.clone()
+
+    th = (H + 15) // 16
+    r_full, a_full, g_full = run(None)
+    g_sum = torch.zeros_like(g_full)
+    for rows in ((0, 3), (3, 4), (4, th)):
+        r, a, g = run(rows)
+        y0, y1 = rows[0] * 16, min(rows[1] * 16, H)
+        assert torch.equal(r[y0:y1], r_full[y0:y1]) and torch.equal(a[y0:y1], a_full[y0:y1])
+        assert float(r[:y0].abs().max() if y0 else 0) == 0 and float(r[y1:].abs().max() if y1 < H else 0) == 0
+        g_sum += g
+    assert rel_inf(g_sum, g_full) < 1e-5
