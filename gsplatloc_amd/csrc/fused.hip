@@ -335,15 +335,18 @@ __global__ __launch_bounds__(256) void k_fraster_fwd(
 // 64-lane reduce-scatter of 32 per-lane values: after the call lanes 2v and 2v+1 both hold the
 // wave-wide sum of v[index v].  Steps: permlane32/16 swaps (cross-row), then DPP row mirrors and
 // quad permutes; 16+8 swaps, 24+4+2+1 adds/selects instead of 32 x 6 DPP adds.
+// v_permlane32_swap vdst, vsrc: lanes 32-63 of vdst trade places with lanes 0-31 of vsrc, so
+// afterwards vdst = [a.lo, b.lo] and vsrc = [a.hi, b.hi]; their sum gives the low half-wave
+// a[i]+a[i+32] and the high half-wave b[i-32]+b[i].  v_permlane16_swap does the same between
+// odd rows of vdst and even rows of vsrc.  Inline asm (with the 2 wait states the hazard rule
+// asks for after a VALU write) because both registers are outputs.
 __device__ __forceinline__ float swap_add32(float lo_keep, float hi_keep) {
-  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, lo_keep),
-                                            __builtin_bit_cast(unsigned, hi_keep), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo_keep), "+v"(hi_keep));
+  return lo_keep + hi_keep;
 }
 __device__ __forceinline__ float swap_add16(float lo_keep, float hi_keep) {
-  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, lo_keep),
-                                            __builtin_bit_cast(unsigned, hi_keep), false, false);
-  return __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo_keep), "+v"(hi_keep));
+  return lo_keep + hi_keep;
 }
 __device__ __forceinline__ float reduce_scatter32(float (&v)[32], int lane) {
   float a[16], b[8], c[4], d[2];
@@ -885,5 +888,23 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
     GSL_CHECK_LAUNCH();
   }
+  return GSL_OK;
+}
+
+// ---- self-test hook for the 64-lane reduce-scatter (used by tests/test_gpu_parity.py) ----
+namespace gsl {
+__global__ void k_debug_reduce_scatter(const float* __restrict__ in /*[64][32]*/, float* __restrict__ out /*[64]*/) {
+  int lane = threadIdx.x;
+  float v[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v[k] = in[lane * 32 + k];
+  out[lane] = reduce_scatter32(v, lane);
+}
+}  // namespace gsl
+
+extern "C" int gsl_debug_reduce_scatter(const float* in, float* out, void* stream) {
+  if (!in || !out) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_debug_reduce_scatter, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+  GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

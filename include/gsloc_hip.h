@@ -187,6 +187,10 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
+/* Self-test hook: out[l] = sum over the 64 lanes of in[lane][l/2] (the wave reduce-scatter the
+ * compositing backward uses); one wave, in[64][32], out[64]. */
+int gsl_debug_reduce_scatter(const float* in, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
