@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gaussians/s, forward + backward, of the GsplatLoc render hot path.
+
+One "step" = one full pass of the path BASELINE.json names on a batch of synthetic input:
+projection + SH colour -> tile binning + per-tile depth sort -> alpha compositing ("RGB+ED",
+the reference's call, /root/reference/src/my_gsplat/model.py:195-213) -> backward from a given
+depth-channel gradient to every Gaussian input and to the 4x4 view matrix.  Inputs are resident
+in HBM before the timed region.  Workload "R" of SURVEY.md 8(d): N = 1,000,000 Gaussians,
+1200x680, sigma_px = 1.0 (I/N ~ 2.4 tile intersections per Gaussian).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): screen-tile rows are
+split across ranks, every rank renders and back-propagates its strip for all N Gaussians, and
+the 12+4 pose-gradient floats are summed with ONE all-reduce per step (strong scaling: the
+frame is fixed, value = Gaussians of the frame / step time).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=680)
+    ap.add_argument("--sigma-px", type=float, default=1.0)
+    ap.add_argument("--order", choices=["random", "raster"], default="random")
+    ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, I, P, D, n_tiles, full):
+    """BASELINE.md section 3 byte model, per stage (bytes per step)."""
+    import math
+    p = math.ceil((32 + math.ceil(math.log2(max(n_tiles, 2)))) / 8)
+    g = 1 if full else 0
+    return {
+        "project_fwd": N * 68,
+        "bin": N * 16 + I * 12 + I * 24 * p + I * 8 + n_tiles * 4,
+        "raster_fwd": I * (28 + 4 * D) + P * (4 * D + 8),
+        "raster_bwd": I * (28 + 4 * D) + P * (4 * D + 12) + 2 * I * (24 + 4 * D),
+        "project_bwd": N * (64 + 4 * D) + N * 40 * g,
+    }
+
+
+def cpu_baseline(args):
+    """The CPU oracle (pure PyTorch restatement, the 'port') timed on the host cores on a bounded
+    sample of the same workload: N/16 Gaussians on a (W/4)x(H/4) image, same sigma_px and density
+    (SURVEY.md 8d).  Threads = min(host cores, 16): a 1-GPU box exposes a 16-core share."""
+    from oracle import gsplat_oracle as G
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    n, w, h = args.n // 16, args.width // 4, args.height // 4
+    sc = random_scene(n, w, h, sigma_px=args.sigma_px)
+    V = torch.linalg.inv(perturbed_pose())[None]
+    g = torch.Generator().manual_seed(1)
+    vd = torch.randn(1, h, w, generator=g)
+
+    def step():
+        ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "sh")]
+        Vg = V.clone().requires_grad_()
+        rc, ra, _ = G.rasterization(*ins, Vg, sc["K"][None], w, h, sh_degree=1, render_mode="RGB+ED")
+        (rc[..., 3] * vd).sum().backward()
+
+    step()
+    ts = []
+    for _ in range(2):
+        t = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t)
+    dt = sorted(ts)[0]
+    return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/gsplat_oracle.py fp32, N={n} on {w}x{h} (N/16, W/4 x H/4 of the workload), "
+                      f"fwd+bwd, best of 2 after warm-up, {dt:.2f} s/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.parallel import strip_rows
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    N, W, H = args.n, args.width, args.height
+    sc = random_scene(N, W, H, sigma_px=args.sigma_px, device=dev, order=args.order)
+    viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    K = sc["K"].contiguous()
+    th = (H + 15) // 16
+    full = not args.pose_only
+
+    # ---- tile-row strip of this rank (balanced on a calibration pass) -------------------------
+    rows = (0, th)
+    n_local = N
+    if world > 1:
+        # once per frame (untimed): balance strips on a full binning pass, keep the Gaussians that can reach
+        # this rank's strip (1-tile guard band), the rest never touch its pixels
+        from gsplatloc_amd.parallel import gaussians_for_strip
+        cal = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
+        cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+        rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank]
+        idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
+        for k in ("means", "quats", "scales", "opacities", "sh"):
+            sc[k] = sc[k][idx].contiguous()
+        n_local = int(idx.numel())
+        del cal
+    ctx = RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full)
+    n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+    g = torch.Generator().manual_seed(1)
+    v_render = torch.zeros(H, W, 4)
+    v_render[..., 3] = torch.randn(H, W, generator=g)
+    v_render = v_render.to(dev)
+    v_alphas = torch.zeros(H, W, 1, device=dev)
+    pose_grad = torch.zeros(16, device=dev)
+    args_in = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+
+    def step():
+        ctx.forward(*args_in)
+        grads = ctx.backward(v_render, v_alphas, full=full)
+        if dist is not None:
+            pose_grad.copy_(grads["viewmat"].reshape(16))
+            dist.all_reduce(pose_grad)
+
+    graph = None
+    side = torch.cuda.Stream()
+    if not args.no_graph and dist is None:
+        # one iteration = a fixed sequence of 10 launches: replay it as a single HIP graph
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                step()
+        torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n_total = ctx.check_capacity()
+    ms = dt / args.steps * 1e3
+
+    # ---- per-kernel durations: HIP events on the launch stream, same steps, second pass -------
+    stage_ms = {}
+    if rank == 0:
+        from gsplatloc_amd import context as C
+        stage_ms = C.time_stages(ctx, args_in, v_render, v_alphas, full, steps=min(args.steps, 20))
+
+    if rank == 0:
+        I_all = n_total if world == 1 else None
+        P = W * H
+        bytes_stage = algorithmic_bytes(n_local, n_total, P if world == 1 else (rows[1] - rows[0]) * 16 * W, 4,
+                                        ctx.n_tiles, full)
+        dom = max(stage_ms, key=stage_ms.get) if stage_ms else "raster_bwd"
+        dom_ms = stage_ms.get(dom, float("nan"))
+        achieved = bytes_stage[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms else None
+        out = {
+            "metric": "Gaussians/s fwd+bwd @1M splats 1200x680",
+            "value": N / (dt / args.steps),
+            "unit": "Gaussians/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"R: {N} random Gaussians ({args.order} order), {W}x{H}, sigma_px={args.sigma_px}, "
+                            f"render_mode=RGB+ED sh_degree=1, backward from a depth-channel gradient, "
+                            f"{'full per-Gaussian gradients + pose gradient' if full else 'pose gradient only'}",
+                "intersections_per_gaussian": (n_total / N) if world == 1 else None,
+                "strip_intersections_rank0": n_total, "tile_rows_rank0": list(rows), "gaussians_rank0": n_local,
+                "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
+                "launch": "hipGraph replay" if graph is not None else "eager",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_stage[dom], "avg_launch_ms": dom_ms,
+                "whole_step": {"algorithmic_bytes": sum(bytes_stage.values()),
+                               "achieved_GBps": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9,
+                               "frac": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9 / 8000.0},
+                "stage_ms": stage_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -266,8 +266,9 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* a, int n, int tid, int nt
 // workgroup barrier (a wave's LDS operations complete in order), which leaves 2-5 s_barriers
 // per sort instead of log^2(P)/2.
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
-  int P = 1;
-  while (P < n) P <<= 1;
+  int lgP = 0;
+  while ((1 << lgP) < n) ++lgP;
+  int P = 1 << lgP;
   if (P < 2) return;
   int nw = P >= 512 ? 4 : (P >= 256 ? 2 : 1);
   int S = P / nw;           // keys per wave segment
@@ -275,14 +276,15 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
   int wv = tid >> 6, lane = tid & 63;
   bool work = wv < nw;
   int pbase = wv * pairs_w;
-  for (int k = 2; k <= P; k <<= 1) {
-    int hk = k >> 1;
+  for (int lk = 1; lk <= lgP; ++lk) {  // stage k = 2^lk
+    int k = 1 << lk, hk = k >> 1;
     if (work) {
       for (int q = lane; q < pairs_w; q += 64) {
         int i = pbase + q;
-        int blk = i / hk, off = i - blk * hk;
-        int lo = blk * k + off;
-        int hi = blk * k + (k - 1 - off);
+        int off = i & (hk - 1);
+        int base = (i >> (lk - 1)) << lk;
+        int lo = base + off;
+        int hi = base + (k - 1 - off);
         if (hi < n) {
           uint64_t x = a[lo], y = a[hi];
           if (x > y) { a[lo] = y; a[hi] = x; }
@@ -291,12 +293,12 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
     }
     if (k > S) __syncthreads();
     else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-    for (int j = hk >> 1; j >= 1; j >>= 1) {
+    for (int lj = lk - 2; lj >= 0; --lj) {  // distance j = 2^lj
+      int j = 1 << lj;
       if (work) {
         for (int q = lane; q < pairs_w; q += 64) {
           int i = pbase + q;
-          int blk = i / j, off = i - blk * j;
-          int lo = blk * 2 * j + off;
+          int lo = ((i >> lj) << (lj + 1)) + (i & (j - 1));
           int hi = lo + j;
           if (hi < n) {
             uint64_t x = a[lo], y = a[hi];
@@ -304,8 +306,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
           }
         }
       }
-      // the NEXT sub-step (distance j/2, or the next stage's mirror over k*2) decides the fence:
-      // a barrier is needed whenever this or the next sub-step crosses segments
+      // a barrier is needed whenever this or the next sub-step crosses wave segments
       bool cross = (2 * j > S) || (j > 1 ? (j > S) : (2 * k > S));
       if (cross) __syncthreads();
       else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }

@@ -211,11 +211,23 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
   for (int y = ymin; y < ymax; ++y)
     for (int x = xmin; x < xmax; ++x) atomicAdd(&s_cnt[y * tile_w + x - tbase], 1);
   __syncthreads();
-  for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) {
-    int c = s_cnt[k];
-    if (c) {
-      s_base[k] = tile_offsets[tbase + k] + atomicAdd(&cursors[tbase + k], c);
-      s_cnt[k] = 0;
+  // one returning global atomic per distinct tile reserves this workgroup's span of the bucket;
+  // all of a thread's atomics are issued before the first result is consumed
+  {
+    int res[GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS];
+#pragma unroll
+    for (int u = 0; u < GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS; ++u) {
+      int k = threadIdx.x + u * GSL_F_BIN_THREADS;
+      int c = (k < nst) ? s_cnt[k] : 0;
+      res[u] = c ? atomicAdd(&cursors[tbase + k], c) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS; ++u) {
+      int k = threadIdx.x + u * GSL_F_BIN_THREADS;
+      if (k < nst) {
+        if (s_cnt[k]) s_base[k] = tile_offsets[tbase + k] + res[u];
+        s_cnt[k] = 0;
+      }
     }
   }
   __syncthreads();
@@ -235,6 +247,21 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bcast(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Lane select driven by a 64-bit scalar mask (v_cndmask_b32_e64 with an SGPR pair).  Measured on
+// MI355X: the VOP2 form that reads VCC issues ~5x slower than this form (9.5 vs 1.8 ns per
+// wave-instruction per SIMD), and hipcc picks the VCC form for plain ?: selects -- so the hot
+// loops keep their predicates as scalar masks (__ballot) and select through this helper.
+__device__ __forceinline__ float sel64(unsigned long long m, float t, float f) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
+}
+__device__ __forceinline__ int sel64i(unsigned long long m, int t, int f) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
 }
 
 template <int D>
@@ -272,9 +299,10 @@ __global__ __launch_bounds__(256) void k_fraster_fwd(
   float pix[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) pix[k] = 0.f;
+  unsigned long long donem = __ballot(done);  // per-lane "pixel finished" as a scalar mask
 
   for (int b = 0; b < nb; ++b) {
-    if (__syncthreads_and(done)) break;
+    if (__syncthreads_and(donem == ~0ull)) break;
     long long bstart = rs + (long long)b * 256;
     int bsize = (int)min((long long)256, re - bstart);
     if (tid < bsize) {
@@ -284,40 +312,36 @@ __global__ __launch_bounds__(256) void k_fraster_fwd(
       if (RGB) sb.s2[tid] = Q2[g];
     }
     __syncthreads();
-    bool wdone = __all(done);
-    for (int c = 0; c < bsize && !wdone; c += 64) {
+    for (int c = 0; c < bsize && donem != ~0ull; c += 64) {
       int e = c + lane;
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f), a2 = a0;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f);
       if (e < bsize) {
         a0 = sb.s0[e];
         a1 = sb.s1[e];
-        if (RGB) a2 = sb.s2[e];
       }
-      bool hit = (fabsf(a0.x - qcx) <= a1.w + 3.5f) && (fabsf(a0.y - qcy) <= a1.w + 3.5f);
-      unsigned long long m = __ballot(hit);
+      unsigned long long m = __ballot(fabsf(a0.x - qcx) <= a1.w + 3.5f) & __ballot(fabsf(a0.y - qcy) <= a1.w + 3.5f);
       while (m) {
-        int l = __ffsll((long long)m) - 1;
+        int t = c + __ffsll((long long)m) - 1;
         m &= m - 1;
-        float sx = bcast(a0.x, l), sy = bcast(a0.y, l), sop = bcast(a0.w, l);
-        float sa = bcast(a1.x, l), sbb = bcast(a1.y, l), sc = bcast(a1.z, l);
-        float dx = sx - px, dy = sy - py;
-        float sigma = 0.5f * (sa * dx * dx + sc * dy * dy) + sbb * dx * dy;
-        float alpha = fminf(GSL_ALPHA_MAX, sop * __expf(-sigma));
-        bool ok = !done && (sigma >= 0.f) && (alpha >= GSL_ALPHA_MIN);
+        // wave-uniform LDS address: one broadcast read per record, operands arrive in VGPRs
+        float4 q0 = sb.s0[t], q1 = sb.s1[t];
+        float dx = q0.x - px, dy = q0.y - py;
+        float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
+        float alpha = fminf(GSL_ALPHA_MAX, q0.w * __expf(-sigma));
         float nT = T * (1.f - alpha);
-        bool stop = ok && (nT <= GSL_T_STOP);
-        bool take = ok && !stop;
-        float vis = take ? alpha * T : 0.f;
+        unsigned long long okm = __ballot(sigma >= 0.f) & __ballot(alpha >= GSL_ALPHA_MIN) & ~donem;
+        unsigned long long stopm = __ballot(nT <= GSL_T_STOP) & okm;
+        unsigned long long takem = okm & ~stopm;
+        float vis = sel64(takem, alpha * T, 0.f);
         if (RGB) {
-          pix[0] += bcast(a2.x, l) * vis;
-          pix[1] += bcast(a2.y, l) * vis;
-          pix[2] += bcast(a2.z, l) * vis;
+          float4 q2 = sb.s2[t];
+          pix[0] += q2.x * vis; pix[1] += q2.y * vis; pix[2] += q2.z * vis;
         }
-        if (DEPTH) pix[D - 1] += bcast(a0.z, l) * vis;
-        cur_idx = take ? (int)bstart + c + l : cur_idx;
-        T = take ? nT : T;
-        done = done || stop;
-        if (__all(done)) { wdone = true; break; }
+        if (DEPTH) pix[D - 1] += q0.z * vis;
+        cur_idx = sel64i(takem, (int)bstart + t, cur_idx);
+        T = sel64(takem, nT, T);
+        donem |= stopm;
+        if (donem == ~0ull) break;
       }
     }
   }
@@ -354,22 +378,25 @@ __device__ __forceinline__ float reduce_scatter32(float (&v)[32], int lane) {
   for (int k = 0; k < 16; ++k) a[k] = swap_add32(v[k], v[16 + k]);  // lanes <32: idx k, lanes >=32: idx 16+k
 #pragma unroll
   for (int k = 0; k < 8; ++k) b[k] = swap_add16(a[k], a[8 + k]);    // odd rows keep the upper half
-  bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+  const unsigned long long B3 = 0xFF00FF00FF00FF00ull;  // lanes with bit 3 / 2 / 1 set
+  const unsigned long long B2 = 0xF0F0F0F0F0F0F0F0ull;
+  const unsigned long long B1 = 0xCCCCCCCCCCCCCCCCull;
+  (void)lane;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     float lo = b[k] + dpp_get<0x140>(b[k]);          // row_mirror pairs lane i with 15-i
     float hi = b[4 + k] + dpp_get<0x140>(b[4 + k]);
-    c[k] = b3 ? hi : lo;
+    c[k] = sel64(B3, hi, lo);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     float lo = c[k] + dpp_get<0x141>(c[k]);          // row_half_mirror pairs i with 7-i (per 8 lanes)
     float hi = c[2 + k] + dpp_get<0x141>(c[2 + k]);
-    d[k] = b2 ? hi : lo;
+    d[k] = sel64(B2, hi, lo);
   }
   float lo = d[0] + dpp_get<0x4E>(d[0]);             // quad_perm [2,3,0,1]
   float hi = d[1] + dpp_get<0x4E>(d[1]);
-  float r = b1 ? hi : lo;
+  float r = sel64(B1, hi, lo);
   r += dpp_get<0xB1>(r);                             // quad_perm [1,0,3,2]
   return r;
 }
@@ -441,6 +468,13 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
   if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
   if (rs >= re) return;
   int nb = (int)((re - rs + 255) / 256);
+  // after the reduce-scatter lanes 2v and 2v+1 hold value v = (splat rh of the group, component rk)
+  unsigned long long insidem = __ballot(inside);
+  int rv = lane >> 1, rh = rv / A, rk = rv - rh * A;
+  bool writer = !(lane & 1) && rh < G;
+  unsigned long long hmask[G];
+#pragma unroll
+  for (int hh = 0; hh < G; ++hh) hmask[hh] = __ballot(rh == hh);
 
   for (int b = 0; b < nb; ++b) {
     long long bend = re - 1 - (long long)b * 256;  // slot t <-> absolute index bend - t (back to front)
@@ -459,76 +493,78 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
     int t_first = (int)max((long long)0, bend - (long long)wave_final);
     for (int c = (t_first / 64) * 64; c < bsize; c += 64) {
       int e = c + lane;
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f), a2 = a0;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f);
       if (e < bsize && e >= t_first) {
         a0 = sb.s0[e];
         a1 = sb.s1[e];
-        if (RGB) a2 = sb.s2[e];
       }
-      bool hit = (fabsf(a0.x - qcx) <= a1.w + 3.5f) && (fabsf(a0.y - qcy) <= a1.w + 3.5f);
-      unsigned long long m = __ballot(hit);
+      unsigned long long m = __ballot(fabsf(a0.x - qcx) <= a1.w + 3.5f) & __ballot(fabsf(a0.y - qcy) <= a1.w + 3.5f);
       while (m) {
         float vals[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) vals[k] = 0.f;
+        vals[30] = 0.f; vals[31] = 0.f;
         int slot[G];
 #pragma unroll
         for (int h = 0; h < G; ++h) {
-          slot[h] = -1;
-          // next hit this wave actually touches
-          bool found = false;
-          int l = 0;
-          bool valid = false;
-          float dx = 0.f, dy = 0.f, sa = 0.f, sbb = 0.f, sc = 0.f, sop = 0.f, vis = 0.f, alpha = 0.f;
-          while (m && !found) {
-            l = __ffsll((long long)m) - 1;
+          // next staged splat that some pixel of this quadrant actually composited
+          unsigned long long validm = 0, capm = 0;
+          int t = 0;
+          float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+          float dx = 0.f, dy = 0.f, vis = 0.f, alpha = 0.f;
+          while (m && !validm) {
+            t = c + __ffsll((long long)m) - 1;
             m &= m - 1;
-            float sx = bcast(a0.x, l), sy = bcast(a0.y, l);
-            sop = bcast(a0.w, l);
-            sa = bcast(a1.x, l); sbb = bcast(a1.y, l); sc = bcast(a1.z, l);
-            dx = sx - px; dy = sy - py;
-            float sigma = 0.5f * (sa * dx * dx + sc * dy * dy) + sbb * dx * dy;
+            q0 = sb.s0[t];
+            q1 = sb.s1[t];
+            dx = q0.x - px; dy = q0.y - py;
+            float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
             vis = __expf(-sigma);
-            alpha = fminf(GSL_ALPHA_MAX, sop * vis);
-            valid = inside && ((bend - (c + l)) <= (long long)bin_final) && (sigma >= 0.f) &&
-                    (alpha >= GSL_ALPHA_MIN);
-            found = __any(valid);
+            float opv = q0.w * vis;
+            alpha = fminf(GSL_ALPHA_MAX, opv);
+            validm = insidem & __ballot((int)(bend - t) <= bin_final) & __ballot(sigma >= 0.f) &
+                     __ballot(alpha >= GSL_ALPHA_MIN);
+            capm = __ballot(opv <= GSL_ALPHA_MAX);
           }
-          if (!found) continue;
-          slot[h] = c + l;
-          float colv[D];
-          if (RGB) { colv[0] = bcast(a2.x, l); colv[1] = bcast(a2.y, l); colv[2] = bcast(a2.z, l); }
-          if (DEPTH) colv[D - 1] = bcast(a0.z, l);
-          if (valid) {
-            float ra = 1.f / (1.f - alpha);
-            T *= ra;
-            float fac = alpha * T;
-            float v_alpha = 0.f;
+          if (!validm) {
+            slot[h] = -1;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-              vals[h * A + 6 + k] = fac * vc[k];
-              v_alpha += (colv[k] * T - buf[k] * ra) * vc[k];
-              buf[k] += colv[k] * fac;
-            }
-            v_alpha += T_final * ra * va;
-            if (sop * vis <= GSL_ALPHA_MAX) {
-              float v_sigma = -sop * vis * v_alpha;
-              vals[h * A + 0] = v_sigma * (sa * dx + sbb * dy);
-              vals[h * A + 1] = v_sigma * (sbb * dx + sc * dy);
-              vals[h * A + 2] = 0.5f * v_sigma * dx * dx;
-              vals[h * A + 3] = v_sigma * dx * dy;
-              vals[h * A + 4] = 0.5f * v_sigma * dy * dy;
-              vals[h * A + 5] = vis * v_alpha;
-            }
+            for (int k = 0; k < A; ++k) vals[h * A + k] = 0.f;
+            continue;
           }
+          slot[h] = t;
+          float colv[D];
+          if (RGB) {
+            float4 q2 = sb.s2[t];
+            colv[0] = q2.x; colv[1] = q2.y; colv[2] = q2.z;
+          }
+          if (DEPTH) colv[D - 1] = q0.z;
+          // lanes that did not composite this splat run with alpha = 0: ra = 1, fac = 0, so T, buf
+          // and every gradient term below stay untouched / zero without per-value selects
+          float am = sel64(validm, alpha, 0.f);
+          float ra = __builtin_amdgcn_rcpf(1.f - am);
+          T *= ra;
+          float fac = am * T;
+          float v_alpha = T_final * ra * va;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            vals[h * A + 6 + k] = fac * vc[k];
+            v_alpha += (colv[k] * T - buf[k] * ra) * vc[k];
+            buf[k] += colv[k] * fac;
+          }
+          float vism = sel64(validm & capm, vis, 0.f);  // alpha clamped at 0.999 => no geometric gradient
+          float v_sigma = -q0.w * vism * v_alpha;
+          vals[h * A + 0] = v_sigma * (q1.x * dx + q1.y * dy);
+          vals[h * A + 1] = v_sigma * (q1.y * dx + q1.z * dy);
+          vals[h * A + 2] = 0.5f * v_sigma * dx * dx;
+          vals[h * A + 3] = v_sigma * dx * dy;
+          vals[h * A + 4] = 0.5f * v_sigma * dy * dy;
+          vals[h * A + 5] = vism * v_alpha;
         }
-        if (slot[0] < 0) break;  // no touched splat left in this chunk
+        if (slot[0] < 0) break;  // nothing left in this chunk for this quadrant
         float r = reduce_scatter32(vals, lane);
-        int v = lane >> 1, h = v / A, k = v - h * A;
         int sl = -1;
 #pragma unroll
-        for (int hh = 0; hh < G; ++hh) sl = (h == hh) ? slot[hh] : sl;
-        if (!(lane & 1) && h < G && sl >= 0) atomicAdd(&sb.acc[sl * AP + k], r);
+        for (int hh = 0; hh < G; ++hh) sl = sel64i(hmask[hh], slot[hh], sl);
+        if (writer && sl >= 0) atomicAdd(&sb.acc[sl * AP + rk], r);
       }
     }
     __syncthreads();

@@ -23,13 +23,20 @@ def replica_intrinsics(W: int = 1200, H: int = 680, dtype=torch.float32) -> torc
     return torch.tensor([[fx, 0.0, (W - 1) / 2.0], [0.0, fy, (H - 1) / 2.0], [0.0, 0.0, 1.0]], dtype=dtype)
 
 
-def random_scene(N: int, W: int, H: int, seed: int = 42, sigma_px: float = 1.0, device="cpu") -> Dict:
+def random_scene(N: int, W: int, H: int, seed: int = 42, sigma_px: float = 1.0, device="cpu",
+                 order: str = "random") -> Dict:
+    """order="raster" sorts the Gaussians by the pixel they project to at the identity pose (row-major),
+    the order GsplatLoc's clouds have: one Gaussian per pixel of the previous depth frame
+    (/root/reference/src/data/Image.py:29,35)."""
     g = torch.Generator().manual_seed(seed)
     K = replica_intrinsics(W, H)
     fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
     u = torch.rand(N, generator=g) * W
     v = torch.rand(N, generator=g) * H
     z = 1.0 + 4.0 * torch.rand(N, generator=g)
+    if order == "raster":
+        perm = torch.argsort(torch.floor(v) * W + u)
+        u, v, z = u[perm], v[perm], z[perm]
     means = torch.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], -1)
     quats = torch.tensor([1.0, 0.0, 0.0, 0.0]).repeat(N, 1)
     scales = (max(sigma_px, 1e-4) * z / fx)[:, None].repeat(1, 3)

@@ -1,0 +1,16 @@
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gsplatloc_amd as A
+from gsplatloc_amd.synthetic import random_scene, perturbed_pose
+N, W, H = int(sys.argv[1]), 1200, 680
+sig = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+sc = random_scene(N, W, H, sigma_px=sig, device='cuda')
+V = torch.linalg.inv(perturbed_pose()).cuda()[None]
+g = torch.Generator().manual_seed(1)
+v = torch.zeros(1, H, W, 4); v[..., 3] = torch.randn(1, H, W, generator=g); v = v.cuda()
+for _ in range(2):
+    Vg = V.clone().requires_grad_()
+    rc, ra, meta = A.rasterization(means=sc['means'], quats=sc['quats'], scales=sc['scales'], opacities=sc['opacities'], colors=sc['sh'],
+        sh_degree=1, viewmats=Vg, Ks=sc['K'][None], width=W, height=H, packed=False, render_mode='RGB+ED')
+    rc.backward(v)
+torch.cuda.synchronize()
