@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void k_fraster_fwd(
         int t = c + __ffsll((long long)m) - 1;
         m &= m - 1;
         // wave-uniform LDS address: one broadcast read per record, operands arrive in VGPRs
+        // (requesting the next survivor's records early was measured slower: more VGPRs, same issue rate)
         float4 q0 = sb.s0[t], q1 = sb.s1[t];
         float dx = q0.x - px, dy = q0.y - py;
         float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
@@ -413,64 +414,32 @@ struct FStageB {
   uint16_t list[4][64];
 };
 
-template <int D, bool ED>
-__global__ __launch_bounds__(256) void k_fraster_bwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
-    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc) {
+// Batch loop of the compositing backward.  CG = number of colour channels that carry an upstream
+// gradient in this tile: D (all of them) or 1 (only the depth channel -- the situation of GsplatLoc's
+// depth + edge loss, /root/reference/src/my_gsplat/gs_trainer_total.py:126-150, detected per tile at
+// run time).  Per staged splat each lane needs, besides alpha and T,
+//     cdot = sum_k colour_k * v_C_k          (one scalar per lane and splat)
+//     Bp   = sum_{splats behind} fac * cdot - T_final * v_A   (one running scalar per lane)
+// so that v_alpha = T * cdot - ra * Bp; the per-channel "buffer" of the textbook replay folds into Bp.
+template <int D, int CG>
+__device__ __forceinline__ void fraster_bwd_body(
+    FStageB<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
+    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
+    float px, float py, float qcx, float qcy, bool inside, int bin_final, int wave_final, float T_final,
+    const float (&vc)[D], float va) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
-  constexpr int A = FStageB<D>::A;
+  constexpr int A = FStageB<D>::A;    // accumulator row layout: [xy 2][conic 3][opacity 1][colour D]
   constexpr int AP = FStageB<D>::AP;
-  constexpr int G = 32 / A;  // splats reduced per reduce-scatter
-  __shared__ FStageB<D> sb;
-  __shared__ int s_final[4];
-  int tile = ty0 * tile_w + blockIdx.x;
-  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  int j = qx + (lane & 7), i = qy + (lane >> 3);
-  float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
-  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;
-
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs >= re) return;
-
-  size_t pid = inside ? ((size_t)i * W + j) : 0;
-  float Aimg = inside ? alphas[pid] : 0.f;
-  float T_final = 1.f - Aimg;
+  constexpr int AC = 6 + CG;          // values reduced per splat in this variant
+  constexpr int G = 32 / AC;          // splats per reduce-scatter
+  int lane = tid & 63, wv = tid >> 6;
   float T = T_final;
-  int bin_final = inside ? last_ids[pid] : -1;
-  float vc[D], buf[D];
-  float va = inside ? v_alphas[pid] : 0.f;
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    vc[k] = inside ? v_render[pid * D + k] : 0.f;
-    buf[k] = 0.f;
-  }
-  if (ED && inside) {
-    // render[..., D-1] = C_depth / max(A, 1e-10): chain to the accumulated depth and to alpha
-    float dn = render[pid * D + (D - 1)];
-    float vd = vc[D - 1];
-    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
-    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
-  }
-  int wave_final = bin_final;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
-  if (lane == 0) s_final[wv] = wave_final;
-  __syncthreads();
-  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
-  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
-  if (rs >= re) return;
-  int nb = (int)((re - rs + 255) / 256);
-  // after the reduce-scatter lanes 2v and 2v+1 hold value v = (splat rh of the group, component rk)
+  float Bp = -T_final * va;
   unsigned long long insidem = __ballot(inside);
-  int rv = lane >> 1, rh = rv / A, rk = rv - rh * A;
+  // after the reduce-scatter lanes 2v and 2v+1 hold value v = (splat rh of the group, component rc)
+  int rv = lane >> 1, rh = rv / AC, rc = rv - rh * AC;
+  int rk = (rc < 6) ? rc : ((CG == D) ? rc : (6 + D - 1));  // position in the accumulator row
   bool writer = !(lane & 1) && rh < G;
   unsigned long long hmask[G];
 #pragma unroll
@@ -485,7 +454,7 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
       sb.id[tid] = g;
       sb.s0[tid] = Q0[g];
       sb.s1[tid] = Q1[g];
-      if (RGB) sb.s2[tid] = Q2[g];
+      if (RGB && CG == D) sb.s2[tid] = Q2[g];
     }
 #pragma unroll
     for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
@@ -501,7 +470,8 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
       unsigned long long m = __ballot(fabsf(a0.x - qcx) <= a1.w + 3.5f) & __ballot(fabsf(a0.y - qcy) <= a1.w + 3.5f);
       while (m) {
         float vals[32];
-        vals[30] = 0.f; vals[31] = 0.f;
+#pragma unroll
+        for (int k = G * AC; k < 32; ++k) vals[k] = 0.f;
         int slot[G];
 #pragma unroll
         for (int h = 0; h < G; ++h) {
@@ -509,14 +479,16 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
           unsigned long long validm = 0, capm = 0;
           int t = 0;
           float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-          float dx = 0.f, dy = 0.f, vis = 0.f, alpha = 0.f;
+          float dx = 0.f, dy = 0.f, gx = 0.f, gy = 0.f, vis = 0.f, alpha = 0.f;
           while (m && !validm) {
             t = c + __ffsll((long long)m) - 1;
             m &= m - 1;
             q0 = sb.s0[t];
             q1 = sb.s1[t];
             dx = q0.x - px; dy = q0.y - py;
-            float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
+            gx = q1.x * dx + q1.y * dy;   // d sigma / d dx
+            gy = q1.y * dx + q1.z * dy;   // d sigma / d dy
+            float sigma = 0.5f * (dx * gx + dy * gy);
             vis = __expf(-sigma);
             float opv = q0.w * vis;
             alpha = fminf(GSL_ALPHA_MAX, opv);
@@ -527,37 +499,45 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
           if (!validm) {
             slot[h] = -1;
 #pragma unroll
-            for (int k = 0; k < A; ++k) vals[h * A + k] = 0.f;
+            for (int k = 0; k < AC; ++k) vals[h * AC + k] = 0.f;
             continue;
           }
           slot[h] = t;
-          float colv[D];
-          if (RGB) {
-            float4 q2 = sb.s2[t];
-            colv[0] = q2.x; colv[1] = q2.y; colv[2] = q2.z;
-          }
-          if (DEPTH) colv[D - 1] = q0.z;
-          // lanes that did not composite this splat run with alpha = 0: ra = 1, fac = 0, so T, buf
-          // and every gradient term below stay untouched / zero without per-value selects
+          // lanes that did not composite this splat run with alpha = 0: ra = 1, fac = 0, so T and Bp stay
+          // untouched and every gradient term is zero without per-value selects
           float am = sel64(validm, alpha, 0.f);
           float ra = __builtin_amdgcn_rcpf(1.f - am);
           T *= ra;
           float fac = am * T;
-          float v_alpha = T_final * ra * va;
+          float cdot;
+          if (CG == D) {
+            float colv[D];
+            if (RGB) {
+              float4 q2 = sb.s2[t];
+              colv[0] = q2.x; colv[1] = q2.y; colv[2] = q2.z;
+            }
+            if (DEPTH) colv[D - 1] = q0.z;
+            cdot = 0.f;
 #pragma unroll
-          for (int k = 0; k < D; ++k) {
-            vals[h * A + 6 + k] = fac * vc[k];
-            v_alpha += (colv[k] * T - buf[k] * ra) * vc[k];
-            buf[k] += colv[k] * fac;
+            for (int k = 0; k < D; ++k) {
+              cdot += colv[k] * vc[k];
+              vals[h * AC + 6 + k] = fac * vc[k];
+            }
+          } else {
+            cdot = q0.z * vc[D - 1];
+            vals[h * AC + 6] = fac * vc[D - 1];
           }
+          float v_alpha = T * cdot - ra * Bp;
+          Bp += fac * cdot;
           float vism = sel64(validm & capm, vis, 0.f);  // alpha clamped at 0.999 => no geometric gradient
           float v_sigma = -q0.w * vism * v_alpha;
-          vals[h * A + 0] = v_sigma * (q1.x * dx + q1.y * dy);
-          vals[h * A + 1] = v_sigma * (q1.y * dx + q1.z * dy);
-          vals[h * A + 2] = 0.5f * v_sigma * dx * dx;
-          vals[h * A + 3] = v_sigma * dx * dy;
-          vals[h * A + 4] = 0.5f * v_sigma * dy * dy;
-          vals[h * A + 5] = vism * v_alpha;
+          float hs = 0.5f * v_sigma;
+          vals[h * AC + 0] = v_sigma * gx;
+          vals[h * AC + 1] = v_sigma * gy;
+          vals[h * AC + 2] = hs * dx * dx;
+          vals[h * AC + 3] = v_sigma * dx * dy;
+          vals[h * AC + 4] = hs * dy * dy;
+          vals[h * AC + 5] = vism * v_alpha;
         }
         if (slot[0] < 0) break;  // nothing left in this chunk for this quadrant
         float r = reduce_scatter32(vals, lane);
@@ -590,6 +570,63 @@ __global__ __launch_bounds__(256) void k_fraster_bwd(
       }
     }
   }
+}
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_fraster_bwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+    float* __restrict__ vacc) {
+  __shared__ FStageB<D> sb;
+  __shared__ int s_final[4];
+  int tile = ty0 * tile_w + blockIdx.x;
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs >= re) return;
+
+  size_t pid = inside ? ((size_t)i * W + j) : 0;
+  float Aimg = inside ? alphas[pid] : 0.f;
+  float T_final = 1.f - Aimg;
+  int bin_final = inside ? last_ids[pid] : -1;
+  float vc[D];
+  float va = inside ? v_alphas[pid] : 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
+  if (ED && inside) {
+    // render[..., D-1] = C_depth / max(A, 1e-10): chain to the accumulated depth and to alpha
+    float dn = render[pid * D + (D - 1)];
+    float vd = vc[D - 1];
+    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
+    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
+  }
+  int wave_final = bin_final;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
+  if (lane == 0) s_final[wv] = wave_final;
+  bool rgb_grad = false;
+  if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
+  int any_rgb = __syncthreads_or(rgb_grad);
+  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
+  // nothing behind block_final was composited by any pixel of the tile: start there
+  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (rs >= re) return;
+  int nb = (int)((re - rs + 255) / 256);
+  if (D == 4 && !any_rgb)
+    fraster_bwd_body<D, 1>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, inside, bin_final,
+                           wave_final, T_final, vc, va);
+  else
+    fraster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, inside, bin_final,
+                           wave_final, T_final, vc, va);
 }
 
 // ------------------------------------------------------------------------------------------------
