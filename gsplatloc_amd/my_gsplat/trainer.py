@@ -1,0 +1,143 @@
+"""Pose tracker: the per-frame body of ``Runner.train``
+(/root/reference/src/my_gsplat/gs_trainer_total.py:53-267) without the W&B / viewer plumbing.
+
+Two engines, same arithmetic:
+  * ``engine="autograd"`` -- the reference's loop verbatim: GSModel + CameraOptModule_quat_tans,
+    losses from ``loss.py``, ``total_loss.backward()``, two Adam optimisers, ExponentialLR.
+    Every rasterization call goes through the gsplat-compatible entry (fused HIP pipeline).
+  * ``engine="context"``  -- same iteration on a preallocated ``RenderContext`` (no allocator
+    traffic, no per-call size read-back, pose-only backward: the Gaussian gradients the reference
+    computes and never consumes are skipped).
+Pose errors: /root/reference/src/eval/utils.py:122-168.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+from torch import Tensor
+
+from ..context import RenderContext
+from .loss import compute_depth_loss, compute_silhouette_loss
+from .model import CameraConfig, CameraOptModule_quat_tans, GsConfig, GSModel
+
+
+def calculate_translation_error(estimated_pose: Tensor, true_pose: Tensor) -> float:
+    """eval/utils.py:122-141."""
+    return float(torch.norm(estimated_pose[:3, 3] - true_pose[:3, 3]))
+
+
+def calculate_rotation_error(estimated_pose: Tensor, true_pose: Tensor) -> float:
+    """eval/utils.py:144-168: rotation angle of R_est R_gt^T in degrees."""
+    Rr = estimated_pose[:3, :3] @ true_pose[:3, :3].T
+    c = torch.clamp((torch.trace(Rr) - 1.0) / 2.0, -1.0, 1.0)
+    return float(torch.acos(c) * 180.0 / math.pi)
+
+
+@dataclass
+class TrackerConfig:
+    """data/base.py:22-43 (OptimizationConfig) + gs_trainer_total.py:34."""
+    max_steps: int = 1000
+    depth_lambda: float = 0.8
+    normal_lambda: float = 0.0
+    early_stop: bool = True
+    patience: int = 200
+    min_step: int = 100  # "if step > 100" (gs_trainer_total.py:171)
+    camera: CameraConfig = CameraConfig()
+    gs: GsConfig = field(default_factory=GsConfig)
+
+
+@dataclass
+class TrackResult:
+    losses: List[float] = field(default_factory=list)
+    best_loss: float = float("inf")
+    best_depth_loss: float = float("inf")
+    best_silhouette_loss: float = float("inf")
+    best_eT: float = float("inf")
+    best_eR: float = float("inf")
+    final_c2w: Optional[Tensor] = None
+    steps: int = 0
+
+
+class PoseTracker:
+    def __init__(self, config: TrackerConfig = TrackerConfig(), engine: str = "autograd"):
+        assert engine in ("autograd", "context")
+        self.config = config
+        self.engine = engine
+
+    def tracking_loss(self, depths: Tensor, depths_gt: Tensor):
+        """gs_trainer_total.py:105-150."""
+        mask = (depths != 0).float()
+        depth_loss = compute_depth_loss(depths * mask, depths_gt * mask, loss_type="l1")
+        silhouette_loss = compute_silhouette_loss(depths * mask, depths_gt * mask, loss_type="l1")
+        total = depth_loss * self.config.depth_lambda + silhouette_loss * (
+            1 - self.config.depth_lambda - self.config.normal_lambda)
+        return total, depth_loss, silhouette_loss
+
+    def track_frame(self, tar_points: Tensor, colors: Tensor, src_depth: Tensor, tar_c2w: Tensor, src_c2w: Tensor,
+                    K: Tensor, width: int, height: int, scales: Optional[Tensor] = None,
+                    verbose: bool = False) -> TrackResult:
+        """One frame pair: Gaussians from the previous frame (``tar_points``), initial pose ``tar_c2w``,
+        target depth ``src_depth`` [1,H,W,1], reference pose ``src_c2w`` for the error read-out."""
+        cfg = self.config
+        max_steps = cfg.max_steps
+        Ks = K.unsqueeze(0)
+        gs_splats = GSModel(tar_points, colors, config=cfg.gs, scales=scales)
+        camera_opt = CameraOptModule_quat_tans(tar_c2w, config=cfg.camera).to(tar_points.device)
+        gamma = 0.2 ** (1.0 / max_steps)
+        schedulers = [torch.optim.lr_scheduler.ExponentialLR(o, gamma=gamma) for o in camera_opt.optimizers]
+        rc = None
+        if self.engine == "context":
+            rc = RenderContext(len(gs_splats), width, height, "RGB+ED", sh_degree=cfg.gs.sh_degree,
+                               K_sh=(cfg.gs.sh_degree + 1) ** 2, device=tar_points.device,
+                               near_plane=cfg.gs.near_plane, far_plane=cfg.gs.far_plane, full_grads=False)
+            opac = torch.sigmoid(gs_splats.opacities).contiguous()
+            sh = torch.cat([gs_splats.sh0, gs_splats.shN], 1).contiguous()
+            statics = (gs_splats.means3d.contiguous(), gs_splats.quats.contiguous(), gs_splats.scales.contiguous(),
+                       opac, sh)
+            with torch.no_grad():
+                rc.calibrate(*statics, torch.linalg.inv(camera_opt()).contiguous(), K.contiguous(), headroom=1.5)
+        res = TrackResult()
+        counter = 0
+        for step in range(max_steps):
+            camera_opt.optimizer_clean()
+            cur_c2w = camera_opt()
+            if rc is None:
+                renders, alphas, _ = gs_splats(camtoworlds=cur_c2w.unsqueeze(0), Ks=Ks, width=width, height=height)
+            else:
+                viewmat = torch.linalg.inv(cur_c2w).contiguous()
+                render, _ = rc.render_autograd(*statics, viewmat, K.contiguous())
+                renders = render.unsqueeze(0)
+            assert renders.shape[-1] == 4
+            depths = renders[..., 3:4]
+            total_loss, depth_loss, silhouette_loss = self.tracking_loss(depths, src_depth)
+            total_loss.backward()
+            with torch.no_grad():
+                lv = total_loss.item()
+                res.losses.append(lv)
+                if cfg.early_stop:
+                    eT = calculate_translation_error(cur_c2w, src_c2w)
+                    eR = calculate_rotation_error(cur_c2w, src_c2w)
+                    if step > cfg.min_step:
+                        if lv < res.best_loss:
+                            res.best_loss = lv
+                            res.best_silhouette_loss = silhouette_loss.item()
+                            res.best_depth_loss = depth_loss.item()
+                            res.best_eT, res.best_eR = eT, eR
+                            counter = 0
+                        else:
+                            counter += 1
+                    if verbose:
+                        print(f"step {step} loss={lv:.8f} eT={eT:.3e} eR={eR:.3e}")
+                res.steps = step + 1
+                res.final_c2w = cur_c2w.detach().clone()
+                if cfg.early_stop and counter >= cfg.patience:
+                    break
+            camera_opt.optimizer_step()
+            for s in schedulers:
+                s.step()
+        if rc is not None:
+            rc.check_capacity()
+        return res

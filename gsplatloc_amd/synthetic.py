@@ -61,3 +61,35 @@ def perturbed_pose(rot_deg: float = 0.5, trans: float = 0.01, seed: int = 7) -> 
     c2w[:3, :3] = R
     c2w[:3, 3] = d
     return c2w.float()
+
+
+def room_depth(W: int, H: int, K: torch.Tensor, c2w: torch.Tensor, half=(2.5, 1.5, 3.0)) -> torch.Tensor:
+    """Depth image [H,W] (z along the optical axis) of an axis-aligned box room |x|<=hx, |y|<=hy, |z|<=hz seen
+    from inside through camera ``c2w`` -- a stand-in for a Replica depth frame (no dataset in the container)."""
+    dt = torch.float64
+    K, c2w = K.to(dt), c2w.to(dt)
+    v, u = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    d_cam = torch.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(u)], -1)  # z = 1
+    d_w = d_cam @ c2w[:3, :3].T
+    o = c2w[:3, 3]
+    t_best = torch.full((H, W), float("inf"), dtype=dt)
+    for ax in range(3):
+        for sgn in (-1.0, 1.0):
+            t = (sgn * half[ax] - o[ax]) / d_w[..., ax]
+            t = torch.where(t > 1e-6, t, torch.full_like(t, float("inf")))
+            t_best = torch.minimum(t_best, t)
+    return t_best.float()  # ray parameter with d_cam.z = 1 == depth along the optical axis
+
+
+def frame_pair(W: int = 160, H: int = 120, rot_deg: float = 0.5, trans: float = 0.01, seed: int = 7) -> Dict:
+    """Synthetic GsplatLoc frame pair (/root/reference/src/data/dataset.py:345-383 in miniature):
+    target cloud = back-projection of frame 0's depth (pose = identity), query depth = frame 1's depth,
+    ground-truth pose of frame 1 = identity perturbed by (rot_deg, trans)."""
+    K = replica_intrinsics(W, H)
+    c2w0 = torch.eye(4)
+    c2w1 = perturbed_pose(rot_deg, trans, seed)
+    d0 = room_depth(W, H, K, c2w0)
+    d1 = room_depth(W, H, K, c2w1)
+    g = torch.Generator().manual_seed(seed)
+    rgb = torch.rand(H * W, 3, generator=g)
+    return dict(K=K, W=W, H=H, depth0=d0, depth1=d1, c2w0=c2w0, c2w1=c2w1, rgb=rgb)

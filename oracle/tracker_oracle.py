@@ -219,7 +219,7 @@ def track_frame(
         depths = renders[..., 3:4]
         total, dl, sl = tracking_loss(depths, depth_gt)
         total.backward()
-        lv = float(total)
+        lv = float(total.detach())
         res.losses.append(lv)
         eT = calculate_translation_error(c2w.detach(), gt_c2w)
         eR = calculate_rotation_error(c2w.detach(), gt_c2w)
