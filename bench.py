@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="dev: run the N-rank path with every rank on cuda:0 and a gloo (host) all-reduce")
     return ap.parse_args()
 
 
@@ -99,13 +101,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from gsplatloc_amd.context import RenderContext
@@ -148,8 +155,13 @@ def main():
         ctx.forward(*args_in)
         grads = ctx.backward(v_render, v_alphas, full=full)
         if dist is not None:
-            pose_grad.copy_(grads["viewmat"].reshape(16))
-            dist.all_reduce(pose_grad)
+            if args.rehearse_on_one_gpu:
+                host = grads["viewmat"].reshape(16).cpu()
+                dist.all_reduce(host)
+                pose_grad.copy_(host)
+            else:
+                pose_grad.copy_(grads["viewmat"].reshape(16))
+                dist.all_reduce(pose_grad)
 
     graph = None
     side = torch.cuda.Stream()
@@ -180,7 +192,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.rehearse_on_one_gpu else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_total = ctx.check_capacity()

@@ -59,3 +59,37 @@ def all_reduce_pose(buf16: Tensor, group=None) -> Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf16, op=dist.ReduceOp.SUM, group=group)
     return buf16
+
+
+def halo_rows(rows: Tuple[int, int], tile_h: int) -> Tuple[int, int]:
+    """Tile rows a rank must render so that the 3x3 Sobel of its own pixel rows is exact: its strip
+    plus one tile row on each interior side."""
+    return max(rows[0] - 1, 0), min(rows[1] + 1, tile_h)
+
+
+def strip_tracking_loss(depths: Tensor, depths_gt: Tensor, rows: Tuple[int, int], height: int,
+                        depth_lambda: float = 0.8, normal_lambda: float = 0.0, tile_size: int = 16):
+    """This rank's share of the tracker's loss (/root/reference/src/my_gsplat/gs_trainer_total.py:105-150):
+    the L1 depth and L1 Sobel-edge terms of the pixel rows it owns, normalised by the FULL image size, so
+    that the shares of all ranks add up to the single-GPU loss and their pose gradients to its gradient.
+    ``depths`` [1,H,W,1] must be valid on the owned rows and one pixel row beyond (see halo_rows).
+    Returns (total_share, depth_share, silhouette_share)."""
+    from .my_gsplat.loss import sobel
+
+    r0, r1 = rows[0] * tile_size, min(rows[1] * tile_size, height)
+    if r1 <= r0:
+        z = depths.sum() * 0.0
+        return z, z, z
+    h0, h1 = max(r0 - 1, 0), min(r1 + 1, height)  # one pixel row of halo
+    d = depths[:, h0:h1]
+    g = depths_gt[:, h0:h1]
+    mask = (d != 0).float()
+    dm, gm = d * mask, g * mask
+    P = float(depths.shape[1] * depths.shape[2] * depths.shape[0] * depths.shape[3])
+    own = slice(r0 - h0, r0 - h0 + (r1 - r0))
+    depth_share = (dm[:, own] - gm[:, own]).abs().sum() / P
+    ea = sobel(dm.permute(0, 3, 1, 2))
+    eb = sobel(gm.permute(0, 3, 1, 2))
+    sil_share = (ea[:, :, own] - eb[:, :, own]).abs().sum() / P
+    total = depth_share * depth_lambda + sil_share * (1 - depth_lambda - normal_lambda)
+    return total, depth_share, sil_share
