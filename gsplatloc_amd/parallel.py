@@ -24,7 +24,7 @@ def strip_rows(tile_offsets: Tensor, tile_w: int, tile_h: int, world: int) -> Li
     """Split tile rows into `world` contiguous strips with balanced intersection counts.
     tile_offsets: [tile_w*tile_h + 1] exclusive scan from a full-frame binning pass."""
     offs = tile_offsets.detach().to("cpu", torch.int64)
-    row_start = offs[0:tile_w * tile_h + 1:tile_w]  # offset at the start of each tile row (+ total)
+    row_start = offs[0:tile_w * tile_h + 1:tile_w].contiguous()  # offset at the start of each tile row (+ total)
     total = int(row_start[-1])
     bounds = [0]
     for r in range(1, world):

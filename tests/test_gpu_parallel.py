@@ -60,4 +60,4 @@ def test_emulated_ranks_match_single_gpu():
             n_sum += idx.numel()
         assert abs(L_sum - L_full) < 1e-5 * abs(L_full)
         assert float((g_sum - g_full).abs().max() / g_full.abs().max()) < 1e-4
-        assert n_sum < 2.0 * N  # buckets overlap only by guard + halo bands
+        assert n_sum < world * N  # every bucket is a strict subset (strip + halo + guard band)
