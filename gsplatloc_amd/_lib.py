@@ -43,6 +43,10 @@ _SIGNATURES = {
                                      P, P, P, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                      P, P, P, P, P, P, P]),
+    "gsl_px_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                  P, P, P, P]),
+    "gsl_px_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                  P, P, P, P, P, P, P]),
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_debug_reduce_scatter": (c_int, [P, P, P]),

@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from ._lib import check, current_stream, load_library, ptr
-from .fused import _MODES, MAX_STRIP_TILES, tile_n_bits
+from .fused import _MODES, MAX_STRIP_TILES, _raster_fn, tile_n_bits
 
 
 class RenderContext:
@@ -117,7 +117,7 @@ class RenderContext:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
                                      ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, st), "gsl_fused_bin")
-        check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
+        check(_raster_fn(self.lib, 'fwd')(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), st), "gsl_fused_raster_fwd")
@@ -133,7 +133,7 @@ class RenderContext:
         assert not full or self.full_grads, "context was built with full_grads=False"
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
         st = current_stream()
-        check(self.lib.gsl_fused_raster_bwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
+        check(_raster_fn(self.lib, 'bwd')(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), ptr(v_render), ptr(v_alphas), ptr(self.vacc), st),
@@ -201,11 +201,11 @@ def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, f
                                 tile_n_bits(rc.n_tiles), ptr(rc.offs), rc.capacity, ptr(rc.keys),
                                 ptr(rc.flatten_ids), None, ptr(rc.ws), rc.ws_bytes, st), "gsl_fused_bin")
         marks.append(ev())
-        check(lib.gsl_fused_raster_fwd(ptr(rc.Q0), ptr(rc.Q1), ptr(rc.Q2), rc.D, int(rc.ed), rc.W, rc.H, rc.tw,
+        check(_raster_fn(lib, 'fwd')(ptr(rc.Q0), ptr(rc.Q1), ptr(rc.Q2), rc.D, int(rc.ed), rc.W, rc.H, rc.tw,
                                        rc.th, rc.ty0, rc.ty1, ptr(rc.offs), ptr(rc.flatten_ids), rc.capacity,
                                        ptr(rc.render), ptr(rc.alphas), ptr(rc.last_ids), st), "gsl_fused_raster_fwd")
         marks.append(ev())
-        check(lib.gsl_fused_raster_bwd(ptr(rc.Q0), ptr(rc.Q1), ptr(rc.Q2), rc.D, int(rc.ed), rc.W, rc.H, rc.tw,
+        check(_raster_fn(lib, 'bwd')(ptr(rc.Q0), ptr(rc.Q1), ptr(rc.Q2), rc.D, int(rc.ed), rc.W, rc.H, rc.tw,
                                        rc.th, rc.ty0, rc.ty1, ptr(rc.offs), ptr(rc.flatten_ids), rc.capacity,
                                        ptr(rc.render), ptr(rc.alphas), ptr(rc.last_ids), ptr(v_render),
                                        ptr(v_alphas), ptr(rc.vacc), st), "gsl_fused_raster_bwd")

@@ -1,0 +1,457 @@
+// Per-pixel-mask compositing (forward and backward) for the fused pipeline.
+//
+// GsplatLoc's splats are tiny: the reference's kNN scales collapse to the 0.3 px^2 blur (alpha >= 1/255 only
+// within ~1.8 px of the centre, ~10 pixels), and even sigma = 1 px splats cover ~45 of a tile's 256 pixels.
+// Walking a tile's depth-sorted list with all 64 lanes of a wave per splat (raster.hip, and the first fused
+// kernels) keeps 8-35 % of the lanes busy.  Here every lane walks ITS OWN pixel's candidates:
+//
+//   1. a batch of 256 records is staged in LDS once per workgroup (16x16 tile, wave = 8x8 quadrant);
+//   2. the staging threads test their record against the four quadrants; order-preserving compaction
+//      (ballot + mbcnt + a 4x4 count table in LDS) gives each wave the ~35 % of the batch it can see;
+//   3. per chunk of 64 surviving candidates, lane e turns candidate e's bounding box into a column range
+//      and a row range of the quadrant; 8 + 8 ballots transpose that into "which candidates cover column
+//      x / row y"; a lane's 64-bit candidate mask is colmask[x] & rowmask[y];
+//   4. each lane pops the set bits of its own mask in list order (front to back, or back to front in the
+//      backward pass), fetching the record from LDS with a per-lane address.  No cross-lane operation is
+//      needed in the loop, so the lanes diverge freely; the wave runs max-over-lanes iterations per chunk
+//      (~3 for the reference's splats instead of ~22 wave-wide trips).
+//   5. backward: every lane adds its contribution to the splat's LDS accumulator row with ds_add_f32
+//      (lanes work on different splats, so there is nothing to reduce across the wave); rows are flushed
+//      per batch as packed 64-byte global atomics exactly as in fused.hip.
+//
+// Skipped candidates are exactly those the reference loop would `continue` over (alpha < 1/255), so the
+// per-pixel sequence of composited splats -- and therefore every output -- is unchanged.
+#include "gsloc_common.h"
+
+namespace gsl {
+
+template <int D>
+struct PStage {
+  float4 s0[256];
+  float4 s1[256];
+  float4 s2[(D >= 3) ? 256 : 1];
+  uint16_t qlist[4][256];  // per-quadrant candidate slots, in list order
+  int qcnt[4][4];          // [staging wave][quadrant]
+};
+
+// Order-preserving compaction of the staged batch into per-quadrant candidate lists.
+// Call with the record of slot `tid` (valid_rec = slot < bsize).  Two barriers inside.
+// Returns the number of candidates of quadrant `wv`.
+template <typename Stage>
+__device__ __forceinline__ int compact_quadrants(Stage& sb, int tid, bool valid_rec, float x, float y, float r,
+                                                 float tile_x0, float tile_y0) {
+  int lane = tid & 63, wv = tid >> 6;
+  unsigned long long B[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float cx = tile_x0 + 4.f + 8.f * (float)(q & 1), cy = tile_y0 + 4.f + 8.f * (float)(q >> 1);
+    B[q] = __ballot(valid_rec && (fabsf(x - cx) <= r + 3.5f) && (fabsf(y - cy) <= r + 3.5f));
+  }
+  if (lane < 4) {
+    unsigned long long b = lane == 0 ? B[0] : (lane == 1 ? B[1] : (lane == 2 ? B[2] : B[3]));
+    sb.qcnt[wv][lane] = __popcll(b);
+  }
+  __syncthreads();
+  unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if ((B[q] >> lane) & 1ull) {
+      int base = 0;
+      for (int w = 0; w < wv; ++w) base += sb.qcnt[w][q];
+      sb.qlist[q][base + __popcll(B[q] & lt)] = (uint16_t)tid;
+    }
+  }
+  __syncthreads();
+  return sb.qcnt[0][wv] + sb.qcnt[1][wv] + sb.qcnt[2][wv] + sb.qcnt[3][wv];
+}
+
+// Per-lane 64-bit candidate mask of one chunk: bit k set <=> candidate k's box covers this lane's pixel.
+// lo/hi are the candidate's inclusive column (row) ranges inside the quadrant (empty if hi < lo).
+// Must be called with all 64 lanes active (wave-uniform control flow): the 8+8 ballots are wave-uniform
+// and are handed to the lanes of column/row v with two exec-masked moves each (no v_cndmask, no VCC).
+__device__ __forceinline__ void masked_mov2(unsigned& dlo, unsigned& dhi, unsigned long long value,
+                                            unsigned long long lanes) {
+  unsigned vlo = (unsigned)value, vhi = (unsigned)(value >> 32);
+  asm volatile("s_mov_b64 exec, %4\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, -1"
+               : "+v"(dlo), "+v"(dhi)
+               : "s"(vlo), "s"(vhi), "s"(lanes));
+}
+__device__ __forceinline__ void pixel_masks(int lox, int hix, int loy, int hiy, int lane, unsigned& mlo, unsigned& mhi) {
+  unsigned clo = 0, chi = 0, rlo = 0, rhi = 0;
+  (void)lane;
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    unsigned long long mc = __ballot(lox <= v && v <= hix);
+    unsigned long long mr = __ballot(loy <= v && v <= hiy);
+    masked_mov2(clo, chi, mc, 0x0101010101010101ull << v);  // lanes of pixel column v
+    masked_mov2(rlo, rhi, mr, 0xFFull << (8 * v));          // lanes of pixel row v
+  }
+  mlo = clo & rlo;
+  mhi = chi & rhi;
+}
+
+__device__ __forceinline__ void box_range(float centre_rel, float r, int& lo, int& hi) {
+  // pixel centres of the quadrant sit at 0..7 in these coordinates
+  float l = ceilf(centre_rel - r), h = floorf(centre_rel + r);
+  lo = (int)fmaxf(l, 0.f);
+  hi = (int)fminf(h, 7.f);
+}
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_praster_fwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+  constexpr bool RGB = D >= 3;
+  constexpr bool DEPTH = (D == 1) || (D == 4);
+  __shared__ PStage<D> sb;
+  int tile = ty0 * tile_w + blockIdx.x;
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+  bool done = !inside;
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs > re) rs = re;
+  int nb = (int)((re - rs + 255) / 256);
+
+  float T = 1.f;
+  int cur_idx = 0;
+  float pix[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pix[k] = 0.f;
+
+  for (int b = 0; b < nb; ++b) {
+    if (__syncthreads_and(done)) break;
+    long long bstart = rs + (long long)b * 256;
+    int bsize = (int)min((long long)256, re - bstart);
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (tid < bsize) {
+      int g = flatten_ids[bstart + tid];
+      r0 = Q0[g];
+      r1 = Q1[g];
+      sb.s0[tid] = r0;
+      sb.s1[tid] = r1;
+      if (RGB) sb.s2[tid] = Q2[g];
+    }
+    int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
+    for (int c = 0; c < n; c += 64) {
+      if (__all(done)) break;
+      int e = c + lane;
+      int lox = 1, hix = 0, loy = 1, hiy = 0;
+      if (e < n) {
+        int t = sb.qlist[wv][e];
+        float4 a0 = sb.s0[t];
+        float r = sb.s1[t].w;
+        box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
+        box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
+      }
+      unsigned mlo, mhi;
+      pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
+      if (done) { mlo = 0; mhi = 0; }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? mhi : mlo;
+        while (__ballot(m != 0)) {
+          if (m != 0) {
+            int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            int t = sb.qlist[wv][c + half * 32 + bit];
+            float4 q0 = sb.s0[t], q1 = sb.s1[t];
+            float dx = q0.x - px, dy = q0.y - py;
+            float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
+            float alpha = fminf(GSL_ALPHA_MAX, q0.w * __expf(-sigma));
+            if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
+              float nT = T * (1.f - alpha);
+              if (nT <= GSL_T_STOP) {
+                done = true;
+                m = 0;
+                mhi = 0;
+              } else {
+                float vis = alpha * T;
+                if (RGB) {
+                  float4 q2 = sb.s2[t];
+                  pix[0] += q2.x * vis; pix[1] += q2.y * vis; pix[2] += q2.z * vis;
+                }
+                if (DEPTH) pix[D - 1] += q0.z * vis;
+                cur_idx = (int)bstart + t;
+                T = nT;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (inside) {
+    size_t pid = (size_t)i * W + j;
+    float A = 1.f - T;
+    alphas[pid] = A;
+    if (ED) pix[D - 1] = pix[D - 1] / fmaxf(A, 1e-10f);
+#pragma unroll
+    for (int k = 0; k < D; ++k) render[pid * D + k] = pix[k];
+    last_ids[pid] = cur_idx;
+  }
+}
+
+template <int D>
+struct PStageB {
+  static constexpr int A = 6 + D;   // accumulator row: [v_xy 2][v_conic 3][v_opacity 1][v_colour D]
+  static constexpr int AP = A | 1;  // odd LDS pitch
+  float4 s0[256];
+  float4 s1[256];
+  float4 s2[(D >= 3) ? 256 : 1];
+  uint16_t qlist[4][256];
+  int qcnt[4][4];
+  int32_t id[256];
+  float acc[256 * AP];
+  uint16_t list[4][64];
+};
+
+// CG = colour channels that carry an upstream gradient in this tile (D, or 1 = depth only; see fused.hip).
+template <int D, int CG>
+__device__ __forceinline__ void praster_bwd_body(
+    PStageB<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
+    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
+    int txi, int tyi, int qx, int qy, float px, float py, bool inside, int bin_final, int wave_final, float T_final,
+    const float (&vc)[D], float va) {
+  constexpr bool RGB = D >= 3;
+  constexpr bool DEPTH = (D == 1) || (D == 4);
+  constexpr int A = PStageB<D>::A;
+  constexpr int AP = PStageB<D>::AP;
+  int lane = tid & 63, wv = tid >> 6;
+  float T = T_final;
+  float Bp = -T_final * va;  // running  sum_behind(fac * cdot) - T_final * v_A   (see fused.hip)
+
+  for (int b = 0; b < nb; ++b) {
+    long long bend = re - 1 - (long long)b * 256;  // slot t <-> absolute index bend - t (back to front)
+    int bsize = (int)min((long long)256, bend + 1 - rs);
+    __syncthreads();
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (tid < bsize) {
+      int g = flatten_ids[bend - tid];
+      sb.id[tid] = g;
+      r0 = Q0[g];
+      r1 = Q1[g];
+      sb.s0[tid] = r0;
+      sb.s1[tid] = r1;
+      if (RGB && CG == D) sb.s2[tid] = Q2[g];
+    }
+#pragma unroll
+    for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
+    int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
+    // slots below t_first hold splats behind everything this quadrant composited
+    int t_first = (int)max((long long)0, bend - (long long)wave_final);
+    int t_lane = inside ? (int)max((long long)0, bend - (long long)bin_final) : 1 << 30;  // first slot of this pixel
+    for (int c = 0; c < n; c += 64) {
+      int e = c + lane;
+      int lox = 1, hix = 0, loy = 1, hiy = 0;
+      if (e < n) {
+        int t = sb.qlist[wv][e];
+        if (t >= t_first) {
+          float4 a0 = sb.s0[t];
+          float r = sb.s1[t].w;
+          box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
+          box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
+        }
+      }
+      unsigned mlo, mhi;
+      pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? mhi : mlo;
+        while (__ballot(m != 0)) {
+          if (m != 0) {
+            int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            int t = sb.qlist[wv][c + half * 32 + bit];
+            if (t >= t_lane) {
+              float4 q0 = sb.s0[t], q1 = sb.s1[t];
+              float dx = q0.x - px, dy = q0.y - py;
+              float gx = q1.x * dx + q1.y * dy;
+              float gy = q1.y * dx + q1.z * dy;
+              float sigma = 0.5f * (dx * gx + dy * gy);
+              float vis = __expf(-sigma);
+              float opv = q0.w * vis;
+              float alpha = fminf(GSL_ALPHA_MAX, opv);
+              if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
+                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                T *= ra;
+                float fac = alpha * T;
+                float* arow = &sb.acc[t * AP];
+                float cdot;
+                if (CG == D) {
+                  float colv[D];
+                  if (RGB) {
+                    float4 q2 = sb.s2[t];
+                    colv[0] = q2.x; colv[1] = q2.y; colv[2] = q2.z;
+                  }
+                  if (DEPTH) colv[D - 1] = q0.z;
+                  cdot = 0.f;
+#pragma unroll
+                  for (int k = 0; k < D; ++k) {
+                    cdot += colv[k] * vc[k];
+                    atomicAdd(&arow[6 + k], fac * vc[k]);
+                  }
+                } else {
+                  cdot = q0.z * vc[D - 1];
+                  atomicAdd(&arow[6 + D - 1], fac * vc[D - 1]);
+                }
+                float v_alpha = T * cdot - ra * Bp;
+                Bp += fac * cdot;
+                if (opv <= GSL_ALPHA_MAX) {  // alpha clamped at 0.999 => no geometric gradient
+                  float v_sigma = -opv * v_alpha;
+                  float hs = 0.5f * v_sigma;
+                  atomicAdd(&arow[0], v_sigma * gx);
+                  atomicAdd(&arow[1], v_sigma * gy);
+                  atomicAdd(&arow[2], hs * dx * dx);
+                  atomicAdd(&arow[3], v_sigma * dx * dy);
+                  atomicAdd(&arow[4], hs * dy * dy);
+                  atomicAdd(&arow[5], vis * v_alpha);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // Flush the batch: pack non-zero slots so that 16 consecutive lanes add one Gaussian's 64-byte row.
+    {
+      bool nz = false;
+      if (tid < bsize) {
+#pragma unroll
+        for (int k = 0; k < A; ++k) nz = nz || (sb.acc[tid * AP + k] != 0.f);
+      }
+      unsigned long long mask = __ballot(nz);
+      int cnt = __popcll(mask);
+      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+      __syncthreads();
+      int f = lane & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        int gi = i0 + (lane >> 4);
+        if (gi < cnt && f < A) {
+          int sl = sb.list[wv][gi];
+          size_t g = (size_t)sb.id[sl];
+          atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+        }
+      }
+    }
+  }
+}
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_praster_bwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+    float* __restrict__ vacc) {
+  __shared__ PStageB<D> sb;
+  __shared__ int s_final[4];
+  int tile = ty0 * tile_w + blockIdx.x;
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs >= re) return;
+
+  size_t pid = inside ? ((size_t)i * W + j) : 0;
+  float Aimg = inside ? alphas[pid] : 0.f;
+  float T_final = 1.f - Aimg;
+  int bin_final = inside ? last_ids[pid] : -1;
+  float vc[D];
+  float va = inside ? v_alphas[pid] : 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
+  if (ED && inside) {
+    float dn = render[pid * D + (D - 1)];
+    float vd = vc[D - 1];
+    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
+    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
+  }
+  int wave_final = bin_final;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
+  if (lane == 0) s_final[wv] = wave_final;
+  bool rgb_grad = false;
+  if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
+  int any_rgb = __syncthreads_or(rgb_grad);
+  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
+  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (rs >= re) return;
+  int nb = (int)((re - rs + 255) / 256);
+  if (D == 4 && !any_rgb)
+    praster_bwd_body<D, 1>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, txi, tyi, qx, qy, px, py, inside,
+                           bin_final, wave_final, T_final, vc, va);
+  else
+    praster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, txi, tyi, qx, qy, px, py, inside,
+                           bin_final, wave_final, T_final, vc, va);
+}
+
+}  // namespace gsl
+
+#define GSL_P_DISPATCH(D, ED, CALL)                                \
+  if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }      \
+  else if (D == 3) { CALL(3, false); }                             \
+  else if (D == 4) { if (ED) CALL(4, true); else CALL(4, false); } \
+  else return GSL_ERR_BAD_ARG;
+
+extern "C" int gsl_px_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                                 int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                                 const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
+                                 int32_t* last_ids, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids) return GSL_ERR_BAD_ARG;
+  if (capacity > 0 && (!Q0 || !Q1 || !flatten_ids)) return GSL_ERR_BAD_ARG;
+  if (channels >= 3 && capacity > 0 && !Q2) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (ty0 == ty1) return GSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (ty1 - ty0) * tile_w;
+#define CALL_PF(DD, EE)                                                                                       \
+  hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids)
+  GSL_P_DISPATCH(channels, ed, CALL_PF)
+#undef CALL_PF
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_px_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                                 int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                                 const int32_t* flatten_ids, int64_t capacity, const float* render,
+                                 const float* alphas, const int32_t* last_ids, const float* v_render,
+                                 const float* v_alphas, float* vacc, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (capacity == 0 || ty0 == ty1) return GSL_OK;
+  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (ty1 - ty0) * tile_w;
+#define CALL_PB(DD, EE)                                                                                       \
+  hipLaunchKernelGGL((gsl::k_praster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
+  GSL_P_DISPATCH(channels, ed, CALL_PB)
+#undef CALL_PB
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}

@@ -22,6 +22,19 @@ MAX_STRIP_TILES = 8192
 _MODES = {"RGB": (3, False), "D": (1, False), "ED": (1, True), "RGB+D": (4, False), "RGB+ED": (4, True)}
 
 
+def _raster_fn(lib, which: str):
+    """Compositing kernels.  "px" = every lane walks its own pixel's candidate mask (csrc/raster_px.hip),
+    "quad" = the wave walks the list together with ballot culling and a wave reduce-scatter
+    (csrc/fused.hip).  Measured on MI355X (1 M splats, 1200x680): forward px 103-185 us vs quad
+    122-210 us; backward quad 306-475 us vs px 472-1185 us (ds_add_f32 issues at ~80 ns per
+    wave-instruction per CU, 45x slower than ds_add_u32), hence the defaults.
+    GSLOC_RASTER_FWD / GSLOC_RASTER_BWD override."""
+    import os
+    kind = os.environ.get("GSLOC_RASTER_" + which.upper(), "px" if which == "fwd" else "quad")
+    assert kind in ("px", "quad"), kind
+    return getattr(lib, ("gsl_px_raster_" if kind == "px" else "gsl_fused_raster_") + which)
+
+
 def tile_n_bits(n_tiles: int) -> int:
     return int(math.floor(math.log2(n_tiles))) + 1
 
@@ -69,7 +82,7 @@ class _FusedRasterization(torch.autograd.Function):
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, 1, dtype=f32, device=dev)
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
-        check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
+        check(_raster_fn(lib, 'fwd')(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
                                        ptr(last_ids), st), "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
@@ -104,7 +117,7 @@ class _FusedRasterization(torch.autograd.Function):
         v_alphas = v_alphas.contiguous()
         vacc = torch.zeros(N, 16, dtype=f32, device=dev)
         n_isects = ctx.n_isects
-        check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
+        check(_raster_fn(lib, 'bwd')(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
                                        ptr(vacc), st), "gsl_fused_raster_bwd")

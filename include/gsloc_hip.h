@@ -187,6 +187,19 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
+/* Per-pixel-mask compositing (csrc/raster_px.hip): same contract and arguments as
+ * gsl_fused_raster_fwd / gsl_fused_raster_bwd, a different kernel organisation: every lane walks the
+ * candidate list of its own pixel, which suits the pixel-sized splats of the pose tracker. */
+int gsl_px_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                      int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                      const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                      float* render, float* alphas, int32_t* last_ids, void* stream);
+int gsl_px_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                      int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                      const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                      const float* render, const float* alphas, const int32_t* last_ids,
+                      const float* v_render, const float* v_alphas, float* vacc, void* stream);
+
 /* Self-test hook: out[l] = sum over the 64 lanes of in[lane][l/2] (the wave reduce-scatter the
  * compositing backward uses); one wave, in[64][32], out[64]. */
 int gsl_debug_reduce_scatter(const float* in, float* out, void* stream);
