@@ -47,6 +47,12 @@ _SIGNATURES = {
                                   P, P, P, P]),
     "gsl_px_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                   P, P, P, P, P, P, P]),
+    "gsl_loss_ws_bytes": (c_size_t, [c_int, c_int]),
+    "gsl_tracking_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_size_t,
+                                  P]),
+    "gsl_pose_init": (c_int, [P, P, P, c_float, c_float, P, P, P]),
+    "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                              c_float, c_float, c_float, c_int, c_int, c_int, c_int, P, P, P, P]),
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_debug_reduce_scatter": (c_int, [P, P, P]),

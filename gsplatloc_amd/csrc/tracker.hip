@@ -1,0 +1,345 @@
+// Device-side tail of one pose-tracking iteration: the depth + Sobel-edge loss with its gradient, and the
+// pose update (pose chain, two Adam optimisers, exponential LR decay, early-stop bookkeeping).
+// Replaces ~40 small PyTorch/kornia launches and three blocking .item() reads per iteration of
+// /root/reference/src/my_gsplat/gs_trainer_total.py:105-185,265-267 (loss.py:10-59, model.py:79-116,
+// eval/utils.py:122-168) so that a whole iteration is a fixed launch sequence (HIP graph).
+//
+//   loss  = 0.8 * mean|d*m - g*m| + 0.2 * mean|S(d*m) - S(g*m)|,  m = (d != 0) (no gradient),
+//   S(x)  = sqrt(gx^2 + gy^2 + 1e-6), gx/gy = 3x3 Sobel / 8 with replicate padding (kornia.filters.sobel).
+#include "gsloc_common.h"
+
+namespace gsl {
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Sobel of the masked image at (i,j) with replicate padding.  img(i,j) = v * (d != 0).
+template <typename F>
+__device__ __forceinline__ void sobel_at(F img, int i, int j, int H, int W, float& gx, float& gy) {
+  float p[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) p[a][b] = img(clampi(i + a - 1, 0, H - 1), clampi(j + b - 1, 0, W - 1));
+  gx = ((p[0][2] - p[0][0]) + 2.f * (p[1][2] - p[1][0]) + (p[2][2] - p[2][0])) * 0.125f;
+  gy = ((p[2][0] - p[0][0]) + 2.f * (p[2][1] - p[0][1]) + (p[2][2] - p[0][2])) * 0.125f;
+}
+
+// Stage 1: per owned pixel the L1 terms and the edge-loss weights wx = s*gx/S, wy = s*gy/S
+// (s = sign(S_d - S_g)).  render is [H,W,D], depth = channel D-1.  Rows [r0,r1) are owned (loss terms),
+// rows [h0,h1) carry valid depth (owned + halo).  partial[block] = (sum|a-b|, sum|Sa-Sb|).
+__global__ __launch_bounds__(256) void k_loss_stage1(const float* __restrict__ render, int D,
+                                                     const float* __restrict__ gt, int W, int H, int r0, int r1,
+                                                     float* __restrict__ wxy, float* __restrict__ partial) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int nown = (r1 - r0) * W;
+  float l1 = 0.f, le = 0.f;
+  if (idx < nown) {
+    int i = r0 + idx / W, j = idx - (idx / W) * W;
+    auto A = [&](int ii, int jj) { return render[((size_t)ii * W + jj) * D + (D - 1)]; };            // d * m == d
+    auto B = [&](int ii, int jj) {
+      float d = render[((size_t)ii * W + jj) * D + (D - 1)];
+      return d != 0.f ? gt[(size_t)ii * W + jj] : 0.f;                                                // g * m
+    };
+    float a = A(i, j), b = B(i, j);
+    l1 = fabsf(a - b);
+    float gxa, gya, gxb, gyb;
+    sobel_at(A, i, j, H, W, gxa, gya);
+    sobel_at(B, i, j, H, W, gxb, gyb);
+    float Sa = sqrtf(gxa * gxa + gya * gya + 1e-6f), Sb = sqrtf(gxb * gxb + gyb * gyb + 1e-6f);
+    le = fabsf(Sa - Sb);
+    float s = (Sa > Sb) ? 1.f : ((Sa < Sb) ? -1.f : 0.f);
+    wxy[2 * ((size_t)i * W + j)] = s * gxa / Sa;
+    wxy[2 * ((size_t)i * W + j) + 1] = s * gya / Sa;
+  }
+  __shared__ float red[4][2];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float s1 = wave_sum(l1), s2 = wave_sum(le);
+  if (lane == 0) { red[wv][0] = s1; red[wv][1] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    partial[2 * (size_t)blockIdx.x + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// Stage 2: v_depth for every pixel of rows [h0,h1): the adjoint of the replicate-padded Sobel applied to
+// (wx, wy) of the owned rows, plus the L1 term on owned rows; written into v_render[...,D-1].
+__global__ __launch_bounds__(256) void k_loss_stage2(const float* __restrict__ render, int D,
+                                                     const float* __restrict__ gt, const float* __restrict__ wxy,
+                                                     int W, int H, int r0, int r1, int h0, int h1, float depth_w,
+                                                     float edge_w, float inv_P, float* __restrict__ v_render) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int n = (h1 - h0) * W;
+  if (idx >= n) return;
+  int i = h0 + idx / W, j = idx - (idx / W) * W;
+  size_t q = (size_t)i * W + j;
+  float d = render[q * D + (D - 1)];
+  float g = 0.f;
+  if (d != 0.f) {
+    // Sobel taps: Kx[a][b] = (b-1)*(a==1?2:1)/8, Ky[a][b] = (a-1)*(b==1?2:1)/8 at offset (a-1, b-1)
+    float acc = 0.f;
+    for (int pi = max(i - 1, r0); pi <= min(i + 1, r1 - 1); ++pi)
+      for (int pj = max(j - 1, 0); pj <= min(j + 1, W - 1); ++pj) {
+        float wx = wxy[2 * ((size_t)pi * W + pj)], wy = wxy[2 * ((size_t)pi * W + pj) + 1];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) {
+            // tap (a,b) of pixel p reads clamp(p + (a-1, b-1)); it contributes to q when that equals q
+            if (clampi(pi + a - 1, 0, H - 1) == i && clampi(pj + b - 1, 0, W - 1) == j) {
+              float kx = (float)(b - 1) * (a == 1 ? 2.f : 1.f) * 0.125f;
+              float ky = (float)(a - 1) * (b == 1 ? 2.f : 1.f) * 0.125f;
+              acc += wx * kx + wy * ky;
+            }
+          }
+      }
+    g = edge_w * acc;
+    if (i >= r0 && i < r1) {
+      float diff = d - gt[q];
+      g += depth_w * ((diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f));
+    }
+    g *= inv_P;
+  }
+  v_render[q * D + (D - 1)] = g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pose state (device resident, one per tracker):
+//   f[0..3] quat (wxyz)  f[4..6] t      f[7..13] Adam exp_avg   f[14..20] Adam exp_avg_sq
+//   f[21] lr_quat f[22] lr_trans        f[23] best_loss f[24] best_depth f[25] best_edge
+//   f[26] best_eT f[27] best_eR         f[28] last_loss f[29] last_eT f[30] last_eR
+//   i[0] step  i[1] counter  i[2] stopped  i[3] best_step
+// ------------------------------------------------------------------------------------------------
+struct PoseHyper {
+  float beta1, beta2, eps, wd_quat, wd_trans, gamma, depth_w, edge_w, inv_P;
+  int min_step, patience, early_stop, max_steps;
+};
+
+__device__ __forceinline__ void quat_to_R(const float q[4], float R[9], float qh[4], float& qn) {
+  qn = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  float inv = 1.f / fmaxf(qn, 1e-12f);
+  float w = q[0] * inv, x = q[1] * inv, y = q[2] * inv, z = q[3] * inv;
+  qh[0] = w; qh[1] = x; qh[2] = y; qh[3] = z;
+  R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z); R[2] = 2.f * (x * z + w * y);
+  R[3] = 2.f * (x * y + w * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
+  R[6] = 2.f * (x * z - w * y); R[7] = 2.f * (y * z + w * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// c2w = [R(q^)|t]; viewmat = c2w^-1 = [R^T | -R^T t] (rows 0..2; row 3 = 0 0 0 1)
+__device__ __forceinline__ void write_pose(const float q[4], const float t[3], float* c2w, float* viewmat) {
+  float R[9], qh[4], qn;
+  quat_to_R(q, R, qh, qn);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      c2w[r * 4 + c] = R[r * 3 + c];
+      viewmat[r * 4 + c] = R[c * 3 + r];
+    }
+    c2w[r * 4 + 3] = t[r];
+    viewmat[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
+  }
+  for (int c = 0; c < 4; ++c) { c2w[12 + c] = (c == 3) ? 1.f : 0.f; viewmat[12 + c] = (c == 3) ? 1.f : 0.f; }
+}
+
+__global__ void k_pose_init(float* __restrict__ f, int* __restrict__ istate, const float* __restrict__ init_c2w,
+                            float lr_quat, float lr_trans, float* __restrict__ c2w, float* __restrict__ viewmat) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // rotation matrix -> wxyz quaternion (kornia rotation_matrix_to_quaternion, eps = 1e-8)
+  const float* m = init_c2w;
+  float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[4], m11 = m[5], m12 = m[6], m20 = m[8], m21 = m[9], m22 = m[10];
+  float trace = m00 + m11 + m22, q[4];
+  const float eps = 1e-8f;
+  if (trace > 0.f) {
+    float sq = sqrtf(trace + 1.f + eps) * 2.f;
+    q[0] = 0.25f * sq; q[1] = (m21 - m12) / sq; q[2] = (m02 - m20) / sq; q[3] = (m10 - m01) / sq;
+  } else if (m00 > m11 && m00 > m22) {
+    float sq = sqrtf(1.f + m00 - m11 - m22 + eps) * 2.f;
+    q[0] = (m21 - m12) / sq; q[1] = 0.25f * sq; q[2] = (m01 + m10) / sq; q[3] = (m02 + m20) / sq;
+  } else if (m11 > m22) {
+    float sq = sqrtf(1.f + m11 - m00 - m22 + eps) * 2.f;
+    q[0] = (m02 - m20) / sq; q[1] = (m01 + m10) / sq; q[2] = 0.25f * sq; q[3] = (m12 + m21) / sq;
+  } else {
+    float sq = sqrtf(1.f + m22 - m00 - m11 + eps) * 2.f;
+    q[0] = (m10 - m01) / sq; q[1] = (m02 + m20) / sq; q[2] = (m12 + m21) / sq; q[3] = 0.25f * sq;
+  }
+  float t[3] = {m[3], m[7], m[11]};
+  for (int k = 0; k < 4; ++k) f[k] = q[k];
+  for (int k = 0; k < 3; ++k) f[4 + k] = t[k];
+  for (int k = 7; k < 21; ++k) f[k] = 0.f;
+  f[21] = lr_quat; f[22] = lr_trans;
+  const float inf = __builtin_huge_valf();
+  for (int k = 23; k < 31; ++k) f[k] = inf;
+  istate[0] = 0; istate[1] = 0; istate[2] = 0; istate[3] = -1;
+  write_pose(q, t, c2w, viewmat);
+}
+
+// One optimisation step.  v_viewmat[16] = d loss / d viewmat (rows 0..2) summed over ranks already.
+// partial[nb][2] loss sums of this rank (loss_sums_in != null: already reduced (sum_l1, sum_edge) over ranks).
+__global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* __restrict__ istate,
+                                                   const float* __restrict__ v_viewmat,
+                                                   const float* __restrict__ partial, int nb,
+                                                   const float* __restrict__ loss_sums_in,
+                                                   const float* __restrict__ gt_c2w, PoseHyper hp,
+                                                   float* __restrict__ c2w, float* __restrict__ viewmat,
+                                                   float* __restrict__ loss_hist) {
+  __shared__ float red[4][2];
+  __shared__ float sums[2];
+  float a0 = 0.f, a1 = 0.f;
+  if (loss_sums_in == nullptr) {
+    for (int b = threadIdx.x; b < nb; b += 256) { a0 += partial[2 * (size_t)b]; a1 += partial[2 * (size_t)b + 1]; }
+  }
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float s0 = wave_sum(a0), s1 = wave_sum(a1);
+  if (lane == 0) { red[wv][0] = s0; red[wv][1] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (loss_sums_in) { sums[0] = loss_sums_in[0]; sums[1] = loss_sums_in[1]; }
+    else { sums[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0]; sums[1] = red[0][1] + red[1][1] + red[2][1] + red[3][1]; }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (istate[2]) return;  // stopped: keep the state frozen (graph replays may still arrive)
+  int step = istate[0];
+  float depth_loss = sums[0] * hp.inv_P, edge_loss = sums[1] * hp.inv_P;
+  float total = hp.depth_w * depth_loss + hp.edge_w * edge_loss;
+  float q[4] = {f[0], f[1], f[2], f[3]}, t[3] = {f[4], f[5], f[6]};
+  float R[9], qh[4], qn;
+  quat_to_R(q, R, qh, qn);
+  // pose errors of the CURRENT pose vs ground truth (eval/utils.py:122-168)
+  float dt0 = t[0] - gt_c2w[3], dt1 = t[1] - gt_c2w[7], dt2 = t[2] - gt_c2w[11];
+  float eT = sqrtf(dt0 * dt0 + dt1 * dt1 + dt2 * dt2);
+  float tr = 0.f;  // trace(R_est R_gt^T) = sum_ij R_est[i][j] * R_gt[i][j]
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) tr += R[i * 3 + j] * gt_c2w[i * 4 + j];
+  float cs = fminf(1.f, fmaxf(-1.f, (tr - 1.f) * 0.5f));
+  float eR = acosf(cs) * 57.29577951308232f;
+  f[28] = total; f[29] = eT; f[30] = eR;
+  if (loss_hist && step < hp.max_steps) loss_hist[step] = total;
+  if (hp.early_stop && step > hp.min_step) {
+    if (total < f[23]) {
+      f[23] = total; f[24] = depth_loss; f[25] = edge_loss; f[26] = eT; f[27] = eR;
+      istate[1] = 0; istate[3] = step;
+    } else {
+      istate[1] += 1;
+    }
+  }
+  istate[0] = step + 1;
+  if (hp.early_stop && istate[1] >= hp.patience) { istate[2] = 1; return; }  // stop BEFORE the optimiser step
+  if (step + 1 >= hp.max_steps) istate[2] = 1;  // last iteration still takes its optimiser step
+  // ---- pose chain: viewmat = inv(c2w) => v_c2w = -V^T v_V V^T
+  float V[16], vV[16];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) V[r * 4 + c] = R[c * 3 + r];
+    V[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
+  }
+  V[12] = V[13] = V[14] = 0.f; V[15] = 1.f;
+  for (int k = 0; k < 12; ++k) vV[k] = v_viewmat[k];
+  vV[12] = vV[13] = vV[14] = vV[15] = 0.f;
+  float M1[16];  // V^T vV
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) {
+      float s = 0.f;
+      for (int i = 0; i < 4; ++i) s += V[i * 4 + a] * vV[i * 4 + b];
+      M1[a * 4 + b] = s;
+    }
+  float vC[16];  // -(M1 V^T)
+  for (int a = 0; a < 4; ++a)
+    for (int c = 0; c < 4; ++c) {
+      float s = 0.f;
+      for (int b = 0; b < 4; ++b) s += M1[a * 4 + b] * V[c * 4 + b];
+      vC[a * 4 + c] = -s;
+    }
+  float vR[9], vt[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) vR[r * 3 + c] = vC[r * 4 + c];
+    vt[r] = vC[r * 4 + 3];
+  }
+  float w = qh[0], x = qh[1], y = qh[2], z = qh[3];
+  float gq[4];
+  gq[0] = 2.f * (-z * vR[1] + y * vR[2] + z * vR[3] - x * vR[5] - y * vR[6] + x * vR[7]);
+  gq[1] = 2.f * (y * vR[1] + z * vR[2] + y * vR[3] - 2.f * x * vR[4] - w * vR[5] + z * vR[6] + w * vR[7] - 2.f * x * vR[8]);
+  gq[2] = 2.f * (-2.f * y * vR[0] + x * vR[1] + w * vR[2] + x * vR[3] + z * vR[5] - w * vR[6] + z * vR[7] - 2.f * y * vR[8]);
+  gq[3] = 2.f * (-2.f * z * vR[0] - w * vR[1] + x * vR[2] + w * vR[3] - 2.f * z * vR[4] + y * vR[5] + x * vR[6] + y * vR[7]);
+  float dq = gq[0] * w + gq[1] * x + gq[2] * y + gq[3] * z;
+  float grad[7];
+  for (int k = 0; k < 4; ++k) grad[k] = (gq[k] - dq * qh[k]) / fmaxf(qn, 1e-12f);
+  for (int k = 0; k < 3; ++k) grad[4 + k] = vt[k];
+  // ---- Adam (torch.optim.Adam semantics, weight decay added to the gradient), per-group lr
+  float b1p = powf(hp.beta1, (float)(step + 1)), b2p = powf(hp.beta2, (float)(step + 1));
+  float bc1 = 1.f - b1p, bc2s = sqrtf(1.f - b2p);
+  for (int k = 0; k < 7; ++k) {
+    float p = (k < 4) ? q[k] : t[k - 4];
+    float wd = (k < 4) ? hp.wd_quat : hp.wd_trans;
+    float lr = (k < 4) ? f[21] : f[22];
+    float g = grad[k] + wd * p;
+    float m = f[7 + k] * hp.beta1 + (1.f - hp.beta1) * g;
+    float v = f[14 + k] * hp.beta2 + (1.f - hp.beta2) * g * g;
+    f[7 + k] = m; f[14 + k] = v;
+    float denom = sqrtf(v) / bc2s + hp.eps;
+    p -= (lr / bc1) * (m / denom);
+    if (k < 4) q[k] = p; else t[k - 4] = p;
+  }
+  for (int k = 0; k < 4; ++k) f[k] = q[k];
+  for (int k = 0; k < 3; ++k) f[4 + k] = t[k];
+  f[21] *= hp.gamma; f[22] *= hp.gamma;  // ExponentialLR
+  write_pose(q, t, c2w, viewmat);
+}
+
+}  // namespace gsl
+
+extern "C" size_t gsl_loss_ws_bytes(int width, int height) {
+  size_t P = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
+  size_t nb = (P + 255) / 256;
+  return P * 2 * sizeof(float) + nb * 2 * sizeof(float);
+}
+
+extern "C" int gsl_tracking_loss(const float* render, int channels, const float* depth_gt, int width, int height,
+                                 int row0, int row1, float depth_lambda, float edge_lambda, float* v_render,
+                                 float* loss_partials, int* n_partials_host, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  if (width <= 0 || height <= 0 || channels <= 0 || row0 < 0 || row1 > height || row0 > row1) return GSL_ERR_BAD_ARG;
+  if (!render || !depth_gt || !v_render || !ws) return GSL_ERR_BAD_ARG;
+  if (ws_bytes < gsl_loss_ws_bytes(width, height)) return GSL_ERR_WORKSPACE;
+  size_t P = (size_t)width * height;
+  float* wxy = (float*)ws;
+  float* partial = loss_partials ? loss_partials : (wxy + 2 * P);
+  int nown = (row1 - row0) * width;
+  int nb1 = (nown + 255) / 256;
+  if (n_partials_host) *n_partials_host = nb1;
+  if (nown == 0) return GSL_OK;
+  int h0 = row0 > 0 ? row0 - 1 : 0, h1 = row1 < height ? row1 + 1 : height;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gsl::k_loss_stage1, dim3(nb1), dim3(256), 0, st, render, channels, depth_gt, width, height, row0,
+                     row1, wxy, partial);
+  GSL_CHECK_LAUNCH();
+  int n2 = (h1 - h0) * width;
+  hipLaunchKernelGGL(gsl::k_loss_stage2, dim3((n2 + 255) / 256), dim3(256), 0, st, render, channels, depth_gt, wxy,
+                     width, height, row0, row1, h0, h1, depth_lambda, edge_lambda, 1.0f / (float)P, v_render);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, float lr_quat, float lr_trans,
+                             float* c2w, float* viewmat, void* stream) {
+  if (!pose_f || !pose_i || !init_c2w || !c2w || !viewmat) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_pose_init, dim3(1), dim3(64), 0, (hipStream_t)stream, pose_f, pose_i, init_c2w, lr_quat,
+                     lr_trans, c2w, viewmat);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* loss_partials,
+                             int n_partials, const float* loss_sums, const float* gt_c2w, int width, int height,
+                             float depth_lambda, float edge_lambda, float beta1, float beta2, float eps,
+                             float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
+                             int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream) {
+  if (!pose_f || !pose_i || !v_viewmat || !gt_c2w || !c2w || !viewmat) return GSL_ERR_BAD_ARG;
+  if (!loss_partials && !loss_sums) return GSL_ERR_BAD_ARG;
+  if (width <= 0 || height <= 0 || n_partials < 0) return GSL_ERR_BAD_ARG;
+  gsl::PoseHyper hp;
+  hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd_quat = wd_quat; hp.wd_trans = wd_trans; hp.gamma = gamma;
+  hp.depth_w = depth_lambda; hp.edge_w = edge_lambda; hp.inv_P = 1.0f / ((float)width * (float)height);
+  hp.min_step = min_step; hp.patience = patience; hp.early_stop = early_stop; hp.max_steps = max_steps;
+  hipLaunchKernelGGL(gsl::k_pose_step, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_f, pose_i, v_viewmat,
+                     loss_partials, n_partials, loss_sums, gt_c2w, hp, c2w, viewmat, loss_hist);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}

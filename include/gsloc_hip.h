@@ -200,6 +200,32 @@ int gsl_px_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int cha
                       const float* render, const float* alphas, const int32_t* last_ids,
                       const float* v_render, const float* v_alphas, float* vacc, void* stream);
 
+/* ---- tracker tail: loss + pose update on device (csrc/tracker.hip) ----
+ * Replaces the PyTorch/kornia glue of one iteration of GsplatLoc's Runner.train
+ * (/root/reference/src/my_gsplat/gs_trainer_total.py:105-185,265-267; loss.py:10-59; model.py:79-116).
+ *
+ * gsl_tracking_loss: depth L1 + Sobel-edge L1 of render[...,channels-1] against depth_gt[H,W] over the owned
+ *   pixel rows [row0,row1) (whole image: 0,height), normalised by width*height; writes d loss / d depth into
+ *   v_render[...,channels-1] for rows [row0-1,row1+1) and the block sums (sum|a-b|, sum|Sa-Sb|) into
+ *   loss_partials[ceil((row1-row0)*width/256)][2] (inside ws when NULL).  ws: gsl_loss_ws_bytes.
+ * gsl_pose_init : pose state <- init_c2w (wxyz quaternion + translation), zero Adam moments, step 0; writes
+ *   c2w[16] and viewmat[16] = c2w^-1.  pose_f[32] floats, pose_i[4] ints (layout: csrc/tracker.hip).
+ * gsl_pose_step : finish the loss, pose errors vs gt_c2w, early-stop bookkeeping (best loss after min_step,
+ *   patience), pose chain viewmat->(quat,t), two Adam updates (weight decay in the gradient), lr *= gamma,
+ *   new c2w / viewmat; appends the loss to loss_hist[max_steps] (may be NULL).  Does nothing once stopped
+ *   (pose_i[2]).  loss_sums[2] (already summed over ranks) overrides loss_partials when not NULL. */
+size_t gsl_loss_ws_bytes(int width, int height);
+int gsl_tracking_loss(const float* render, int channels, const float* depth_gt, int width, int height,
+                      int row0, int row1, float depth_lambda, float edge_lambda, float* v_render,
+                      float* loss_partials, int* n_partials_host, void* ws, size_t ws_bytes, void* stream);
+int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, float lr_quat, float lr_trans,
+                  float* c2w, float* viewmat, void* stream);
+int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* loss_partials,
+                  int n_partials, const float* loss_sums, const float* gt_c2w, int width, int height,
+                  float depth_lambda, float edge_lambda, float beta1, float beta2, float eps,
+                  float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
+                  int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream);
+
 /* Self-test hook: out[l] = sum over the 64 lanes of in[lane][l/2] (the wave reduce-scatter the
  * compositing backward uses); one wave, in[64][32], out[64]. */
 int gsl_debug_reduce_scatter(const float* in, float* out, void* stream);

@@ -75,3 +75,89 @@ def test_tracker_converges_to_ground_truth_pose():
     e0 = M.calculate_translation_error(fp["c2w0"], fp["c2w1"])
     assert r.losses[-1] < 0.5 * r.losses[0]
     assert r.best_eT < 0.5 * e0, (r.best_eT, e0)
+
+
+def test_fused_loss_kernel_matches_autograd_loss():
+    """gsl_tracking_loss (depth L1 + Sobel-edge L1, value and gradient) vs the PyTorch loss of my_gsplat.loss,
+    whole image and a strip with halo."""
+    import gsplatloc_amd.my_gsplat as M
+    from gsplatloc_amd._lib import check, load_library, ptr
+    from gsplatloc_amd.parallel import strip_tracking_loss
+    lib = load_library()
+    W, H, D = 75, 52, 4
+    g = torch.Generator().manual_seed(5)
+    render = torch.rand(H, W, D, generator=g) * 3 + 0.5
+    render[5:9, 10:30, 3] = 0.0           # holes: mask = (depth != 0)
+    render[:, 0, 3] = 0.0
+    gt = torch.rand(H, W, generator=g) * 3 + 0.5
+    render, gt = render.to(DEV), gt.to(DEV)
+    trk = M.PoseTracker()
+    ws_bytes = lib.gsl_loss_ws_bytes(W, H)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=DEV)
+    for rows in (None, (1, 3)):
+        r = render.clone().requires_grad_()
+        depths = r[None, ..., 3:4]
+        if rows is None:
+            total, dl, sl = trk.tracking_loss(depths, gt[None, ..., None])
+            row0, row1 = 0, H
+        else:
+            total, dl, sl = strip_tracking_loss(depths, gt[None, ..., None], rows, H)
+            row0, row1 = rows[0] * 16, min(rows[1] * 16, H)
+        total.backward()
+        v = torch.zeros(H, W, D, device=DEV)
+        nb = ((row1 - row0) * W + 255) // 256
+        partials = torch.zeros(nb * 2, device=DEV)
+        check(lib.gsl_tracking_loss(ptr(render), D, ptr(gt), W, H, row0, row1, 0.8, 0.2, ptr(v), ptr(partials), None,
+                                    ptr(ws), ws_bytes, None), "loss")
+        torch.cuda.synchronize()
+        sums = partials.view(-1, 2).sum(0) / (W * H)
+        assert abs(float(sums[0]) - float(dl)) < 1e-5 * float(dl) + 1e-9
+        assert abs(float(sums[1]) - float(sl)) < 1e-4 * float(sl) + 1e-9
+        ref = r.grad[..., 3]
+        assert float((v[..., 3] - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-12
+        assert float(v[..., :3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_graph_tracker_matches_pose_tracker(use_graph):
+    """Device-side loss + pose chain + Adam + LR decay + early-stop bookkeeping reproduce the PyTorch loop."""
+    M, fp, K, pts0, pts1, scales0, scales1 = _setup()
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    W, H = fp["W"], fp["H"]
+    src_depth = M.compute_depth_gt(pts1.to(DEV), fp["rgb"].to(DEV), K[None].to(DEV), torch.eye(4, device=DEV)[None], H, W)
+    src_depth = src_depth[None, ..., None]
+    steps = 40
+    cfg = M.TrackerConfig(max_steps=steps, min_step=5, patience=1000)
+    ref = M.PoseTracker(cfg, engine="context").track_frame(
+        pts0.to(DEV), fp["rgb"].to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV), K.to(DEV), W, H,
+        scales=scales0.to(DEV))
+    gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, use_graph=use_graph, poll=10)
+    gt.load_frame(pts0.to(DEV), fp["rgb"].to(DEV), scales0.to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV),
+                  K.to(DEV))
+    res = gt.run()
+    assert res.steps == steps == ref.steps
+    la, lb = torch.tensor(res.losses, dtype=torch.float64), torch.tensor(ref.losses, dtype=torch.float64)
+    assert torch.allclose(la, lb, rtol=2e-3, atol=1e-8), (la, lb)
+    assert abs(res.best_loss - ref.best_loss) < 2e-3 * ref.best_loss
+    assert abs(res.best_eT - ref.best_eT) < 1e-4 and abs(res.best_eR - ref.best_eR) < 2e-3
+    # a second frame on the same tracker (buffers and graph reused)
+    gt.load_frame(pts0.to(DEV), fp["rgb"].to(DEV), scales0.to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV),
+                  K.to(DEV))
+    res2 = gt.run()
+    assert torch.allclose(torch.tensor(res2.losses, dtype=torch.float64), la, rtol=1e-4)
+
+
+def test_graph_tracker_early_stop():
+    M, fp, K, pts0, pts1, scales0, scales1 = _setup()
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    W, H = fp["W"], fp["H"]
+    src_depth = M.compute_depth_gt(pts1.to(DEV), fp["rgb"].to(DEV), K[None].to(DEV), torch.eye(4, device=DEV)[None], H, W)
+    cfg = M.TrackerConfig(max_steps=400, min_step=3, patience=4)
+    gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=8)
+    gt.load_frame(pts0.to(DEV), fp["rgb"].to(DEV), scales0.to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV), K.to(DEV))
+    res = gt.run()
+    ref = M.PoseTracker(cfg, engine="context").track_frame(
+        pts0.to(DEV), fp["rgb"].to(DEV), src_depth[None, ..., None], fp["c2w0"].to(DEV), fp["c2w1"].to(DEV), K.to(DEV),
+        W, H, scales=scales0.to(DEV))
+    assert res.steps < 400
+    assert abs(res.steps - ref.steps) <= 2, (res.steps, ref.steps)  # fp32 ties in "loss < best" may shift the stop by an iteration
