@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--order", choices=["random", "raster"], default="random")
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tracker", action="store_true", help="skip the pose-opt iterations/s side measurement")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank path with every rank on cuda:0 and a gloo (host) all-reduce")
@@ -93,6 +94,39 @@ def cpu_baseline(args):
     return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"oracle/gsplat_oracle.py fp32, N={n} on {w}x{h} (N/16, W/4 x H/4 of the workload), "
                       f"fwd+bwd, best of 2 after warm-up, {dt:.2f} s/step"}
+
+
+def pose_opt_rate(dev):
+    """BASELINE metric 2 (side measurement, rank 0, N=1): pose-optimisation iterations/s of the whole
+    tracker iteration (render fwd+bwd, depth+edge loss, pose chain, 2x Adam, LR decay, early-stop
+    bookkeeping) as one HIP graph, config S of BASELINE.json: ~100k Gaussians, 640x480, 200 iterations."""
+    import gsplatloc_amd.my_gsplat as M
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    from gsplatloc_amd.my_gsplat.geometry import depth_to_points
+    from gsplatloc_amd.synthetic import frame_pair
+
+    W, H, iters = 640, 480, 200
+    fp = frame_pair(W, H, rot_deg=0.3, trans=0.01)
+    K = fp["K"].to(dev)
+    pts0 = depth_to_points(fp["depth0"].to(dev), K)[::3].contiguous()
+    rgb = fp["rgb"].to(dev)[::3].contiguous()
+    pts1 = depth_to_points(fp["depth1"].to(dev), K)
+    scales = M.init_gs_scales(pts0)
+    src = M.compute_depth_gt(pts1, fp["rgb"].to(dev), K[None], torch.eye(4, device=dev)[None], H, W)
+    cfg = M.TrackerConfig(max_steps=iters, min_step=100, patience=10 ** 9)
+    gt = GraphTracker(pts0.shape[0], W, H, cfg, device=dev, poll=50)
+    frame = (pts0, rgb, scales, src, fp["c2w0"].to(dev), fp["c2w1"].to(dev), K)
+    gt.load_frame(*frame)
+    gt.run()
+    gt.load_frame(*frame)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    res = gt.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    return {"config": "S: depth-map-like frame pair, %d Gaussians, 640x480, 200 iterations, HIP graph" % pts0.shape[0],
+            "iters_per_s": res.steps / dt, "ms_per_iter": dt / res.steps * 1e3, "loss_first": res.losses[0],
+            "loss_last": res.losses[-1], "eT_init_m": 0.01, "best_eT_m": res.best_eT}
 
 
 def main():
@@ -248,6 +282,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_tracker:
+            out["pose_opt"] = pose_opt_rate(dev)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
