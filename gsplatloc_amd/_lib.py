@@ -53,6 +53,10 @@ _SIGNATURES = {
     "gsl_pose_init": (c_int, [P, P, P, c_float, c_float, P, P, P]),
     "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                               c_float, c_float, c_float, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "gsl_knn_ws_bytes": (c_size_t, [c_int]),
+    "gsl_knn_cells": (c_int, []),
+    "gsl_knn_count": (c_int, [P, c_int, P, P, c_size_t, P]),
+    "gsl_knn_query": (c_int, [P, c_int, P, P, c_int, P, P, c_size_t, P]),
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_debug_reduce_scatter": (c_int, [P, P, P]),

@@ -7,7 +7,32 @@ import torch
 from torch import Tensor
 
 
+def knn_device(x: Tensor, K: int) -> Tensor:
+    """Exact K nearest neighbours (self included) of a device point cloud: SQUARED distances [N,K],
+    ascending -- csrc/knn.hip (uniform grid, shell search), no host round trip."""
+    from .._lib import check, current_stream, load_library, ptr
+
+    lib = load_library()
+    assert x.is_cuda and x.dim() == 2 and x.shape[1] == 3 and 1 <= K <= 8
+    x = x.detach().to(torch.float32).contiguous()
+    N = x.shape[0]
+    bbox = torch.cat([x.amin(0), x.amax(0)]).contiguous()
+    ws_bytes = lib.gsl_knn_ws_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    st = current_stream()
+    check(lib.gsl_knn_count(ptr(x), N, ptr(bbox), ptr(ws), ws_bytes, st), "gsl_knn_count")
+    cells = lib.gsl_knn_cells()
+    counts = ws[:cells * 4].view(torch.int32)
+    incl = torch.cumsum(counts, 0, dtype=torch.int32)
+    dists = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    check(lib.gsl_knn_query(ptr(x), N, ptr(bbox), ptr(incl), K, ptr(dists), ptr(ws), ws_bytes, st), "gsl_knn_query")
+    return dists
+
+
 def knn(x: Tensor, K: int = 4, squared: bool = True) -> Tensor:
+    if x.is_cuda and K <= 8:
+        d2 = knn_device(x, K)
+        return d2 if squared else torch.sqrt(d2)
     from scipy.spatial import cKDTree
 
     x_np = x.detach().cpu().numpy().astype(np.float64)

@@ -226,6 +226,18 @@ int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const floa
                   float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
                   int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream);
 
+/* ---- per-frame set-up: exact k nearest neighbours on the device (csrc/knn.hip) ----
+ * Stands in for the small_gicp KdTree search of /root/reference/src/my_gsplat/utils.py:16-22.
+ * points[N,3]; bbox[6] = (min x,y,z, max x,y,z) on the device; uniform grid of gsl_knn_cells() cells.
+ * gsl_knn_count fills the per-cell counts at the start of ws (int32[cells]); the caller turns them into an
+ * inclusive cumulative sum incl_offsets[cells] (any device scan); gsl_knn_query then writes the SQUARED
+ * distances to the k <= 8 nearest points (the point itself included), ascending, into dists[N,k]. */
+size_t gsl_knn_ws_bytes(int N);
+int gsl_knn_cells(void);
+int gsl_knn_count(const float* points, int N, const float* bbox, void* ws, size_t ws_bytes, void* stream);
+int gsl_knn_query(const float* points, int N, const float* bbox, const int32_t* incl_offsets, int k,
+                  float* dists, void* ws, size_t ws_bytes, void* stream);
+
 /* Self-test hook: out[l] = sum over the 64 lanes of in[lane][l/2] (the wave reduce-scatter the
  * compositing backward uses); one wave, in[64][32], out[64]. */
 int gsl_debug_reduce_scatter(const float* in, float* out, void* stream);

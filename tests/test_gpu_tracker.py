@@ -161,3 +161,29 @@ def test_graph_tracker_early_stop():
         W, H, scales=scales0.to(DEV))
     assert res.steps < 400
     assert abs(res.steps - ref.steps) <= 2, (res.steps, ref.steps)  # fp32 ties in "loss < best" may shift the stop by an iteration
+
+
+@pytest.mark.parametrize("case", ["depthmap", "random", "duplicates"])
+def test_device_knn_matches_kdtree(case):
+    """csrc/knn.hip vs scipy cKDTree (the stand-in for small_gicp's KdTree, utils.py:16-22): exact k-NN."""
+    import numpy as np
+    from scipy.spatial import cKDTree
+    from gsplatloc_amd.my_gsplat.utils import knn_device
+    g = torch.Generator().manual_seed(3)
+    if case == "depthmap":
+        fp = frame_pair(160, 120)
+        pts = T.depth_to_points(fp["depth0"], fp["K"])
+    elif case == "random":
+        pts = torch.rand(20000, 3, generator=g) * torch.tensor([4.0, 0.3, 2.0]) + torch.tensor([-1.0, 5.0, 0.0])
+    else:
+        pts = torch.rand(3000, 3, generator=g)
+        pts[:700] = 0.0  # invalid-depth pixels all back-project to the origin
+    k = 5
+    d_ref, _ = cKDTree(pts.double().numpy()).query(pts.double().numpy(), k=k)
+    d2 = knn_device(pts.to(DEV), k).cpu().double().numpy()
+    np.testing.assert_allclose(d2, d_ref ** 2, rtol=2e-5, atol=1e-10)
+    # and through the reference-shaped scale initialisation (as-coded: squared distances squared again)
+    import gsplatloc_amd.my_gsplat as M
+    s_dev = M.init_gs_scales(pts.to(DEV)).cpu()
+    s_ref = T.init_gs_scales(pts, as_coded=True)
+    assert torch.allclose(s_dev, s_ref, rtol=1e-4, atol=1e-12)
