@@ -198,34 +198,54 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
   }
 }
 
-template <int D>
+// ---------------------------------------------------------------------------------------------------
+// Backward.  ds_add_f32 issues at ~80 ns per wave-instruction per CU on MI355X (scripts/ubench/ldsatom.hip),
+// so the per-lane walk cannot add into shared accumulators.  Two phases per round of 16 candidates:
+//   phase 1 (lane = pixel): walk the own candidate bits back to front, keep T and the running scalar Bp,
+//            and leave per (pixel, candidate) just  w = vis * v_alpha  (0 when alpha is clamped or the
+//            splat was not composited) and  fac = alpha * T  in an LDS slab rec[candidate][pixel];
+//   phase 2 (4 lanes = one candidate): walk the pixels of the candidate's box, rebuild dx, dy and the
+//            gradient direction from the candidate's own record, and sum
+//            v_xy, v_conic, v_opacity, v_colour over the pixels; two quad DPP adds fold the 4 lanes.
+// Per-(quadrant, candidate) totals leave the workgroup as packed 64-byte atomic rows.
+// ---------------------------------------------------------------------------------------------------
+template <int D, int CG>
 struct PStageB {
-  static constexpr int A = 6 + D;   // accumulator row: [v_xy 2][v_conic 3][v_opacity 1][v_colour D]
-  static constexpr int AP = A | 1;  // odd LDS pitch
+  static constexpr bool RGBS = (D >= 3) && (CG == D);
   float4 s0[256];
   float4 s1[256];
-  float4 s2[(D >= 3) ? 256 : 1];
+  float4 s2[RGBS ? 256 : 1];
   uint16_t qlist[4][256];
   int qcnt[4][4];
   int32_t id[256];
-  float acc[256 * AP];
-  uint16_t list[4][64];
+  float2 rec[4][16][64];      // [wave][candidate of the round][pixel lane] = (w, fac)
+  uint16_t pmask[4][64];      // candidate bits of the round per pixel lane
+  uint16_t box[4][64];        // candidate boxes of the chunk: lox | hix<<4 | loy<<8 | hiy<<12
+  float vcs[4][64][CG];       // upstream colour gradients per pixel lane
+  float tot[4][16][16];       // per-candidate totals of the round, accumulator-row layout
 };
 
-// CG = colour channels that carry an upstream gradient in this tile (D, or 1 = depth only; see fused.hip).
 template <int D, int CG>
 __device__ __forceinline__ void praster_bwd_body(
-    PStageB<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
+    PStageB<D, CG>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
     const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
     int txi, int tyi, int qx, int qy, float px, float py, bool inside, int bin_final, int wave_final, float T_final,
     const float (&vc)[D], float va) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
-  constexpr int A = PStageB<D>::A;
-  constexpr int AP = PStageB<D>::AP;
+  constexpr bool RGBS = PStageB<D, CG>::RGBS;
+  constexpr int A = 6 + D;  // accumulator row: [v_xy 2][v_conic 3][v_opacity 1][v_colour D]
   int lane = tid & 63, wv = tid >> 6;
   float T = T_final;
   float Bp = -T_final * va;  // running  sum_behind(fac * cdot) - T_final * v_A   (see fused.hip)
+  // this pixel's upstream colour gradients, for the candidate-major phase
+  if (CG == D) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) sb.vcs[wv][lane][k] = vc[k];
+  } else {
+    sb.vcs[wv][lane][0] = vc[D - 1];
+  }
+  int c2 = lane >> 2, part = lane & 3;  // phase-2 role: candidate of the round, quarter of its rows
 
   for (int b = 0; b < nb; ++b) {
     long long bend = re - 1 - (long long)b * 256;  // slot t <-> absolute index bend - t (back to front)
@@ -239,10 +259,8 @@ __device__ __forceinline__ void praster_bwd_body(
       r1 = Q1[g];
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
-      if (RGB && CG == D) sb.s2[tid] = Q2[g];
+      if (RGBS) sb.s2[tid] = Q2[g];
     }
-#pragma unroll
-    for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     // slots below t_first hold splats behind everything this quadrant composited
     int t_first = (int)max((long long)0, bend - (long long)wave_final);
@@ -259,16 +277,24 @@ __device__ __forceinline__ void praster_bwd_body(
           box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
         }
       }
+      sb.box[wv][lane] = (uint16_t)((lox & 15) | ((hix & 15) << 4) | ((loy & 15) << 8) | ((hiy & 15) << 12));
       unsigned mlo, mhi;
       pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        unsigned m = half ? mhi : mlo;
+      unsigned long long m64 = ((unsigned long long)mhi << 32) | mlo;
+      if (!__ballot(m64 != 0)) continue;
+#pragma unroll 1
+      for (int rnd = 0; rnd < 4; ++rnd) {
+        unsigned m = (unsigned)(m64 >> (16 * rnd)) & 0xFFFFu;
+        if (!__ballot(m != 0)) continue;
+        int cbase = c + 16 * rnd;
+        sb.pmask[wv][lane] = (uint16_t)m;
+        // ---- phase 1: lane = pixel
         while (__ballot(m != 0)) {
           if (m != 0) {
             int bit = __ffs((int)m) - 1;
             m &= m - 1;
-            int t = sb.qlist[wv][c + half * 32 + bit];
+            int t = sb.qlist[wv][cbase + bit];
+            float w = 0.f, fac = 0.f;
             if (t >= t_lane) {
               float4 q0 = sb.s0[t], q1 = sb.s1[t];
               float dx = q0.x - px, dy = q0.y - py;
@@ -281,64 +307,102 @@ __device__ __forceinline__ void praster_bwd_body(
               if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
                 float ra = __builtin_amdgcn_rcpf(1.f - alpha);
                 T *= ra;
-                float fac = alpha * T;
-                float* arow = &sb.acc[t * AP];
+                fac = alpha * T;
                 float cdot;
                 if (CG == D) {
-                  float colv[D];
+                  cdot = 0.f;
                   if (RGB) {
                     float4 q2 = sb.s2[t];
-                    colv[0] = q2.x; colv[1] = q2.y; colv[2] = q2.z;
+                    cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
                   }
-                  if (DEPTH) colv[D - 1] = q0.z;
-                  cdot = 0.f;
-#pragma unroll
-                  for (int k = 0; k < D; ++k) {
-                    cdot += colv[k] * vc[k];
-                    atomicAdd(&arow[6 + k], fac * vc[k]);
-                  }
+                  if (DEPTH) cdot += q0.z * vc[D - 1];
                 } else {
                   cdot = q0.z * vc[D - 1];
-                  atomicAdd(&arow[6 + D - 1], fac * vc[D - 1]);
                 }
                 float v_alpha = T * cdot - ra * Bp;
                 Bp += fac * cdot;
-                if (opv <= GSL_ALPHA_MAX) {  // alpha clamped at 0.999 => no geometric gradient
-                  float v_sigma = -opv * v_alpha;
-                  float hs = 0.5f * v_sigma;
-                  atomicAdd(&arow[0], v_sigma * gx);
-                  atomicAdd(&arow[1], v_sigma * gy);
-                  atomicAdd(&arow[2], hs * dx * dx);
-                  atomicAdd(&arow[3], v_sigma * dx * dy);
-                  atomicAdd(&arow[4], hs * dy * dy);
-                  atomicAdd(&arow[5], vis * v_alpha);
+                if (opv <= GSL_ALPHA_MAX) w = vis * v_alpha;  // alpha clamped at 0.999 => no geometric gradient
+              }
+            }
+            sb.rec[wv][bit][lane] = make_float2(w, fac);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: 4 lanes = one candidate of the round
+        float acc[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) acc[k] = 0.f;
+        int ci = cbase + c2;
+        int gsl_t = 0;
+        if (ci < n) {
+          unsigned bx = sb.box[wv][16 * rnd + c2];
+          int blox = bx & 15, bhix = (bx >> 4) & 15, bloy = (bx >> 8) & 15, bhiy = (bx >> 12) & 15;
+          gsl_t = sb.qlist[wv][ci];
+          float4 q0 = sb.s0[gsl_t], q1 = sb.s1[gsl_t];
+          for (int row = bloy + part; row <= bhiy; row += 4) {
+            for (int col = blox; col <= bhix; ++col) {
+              int pl = row * 8 + col;
+              if ((sb.pmask[wv][pl] >> c2) & 1) {
+                float2 wf = sb.rec[wv][c2][pl];
+                float dx = q0.x - ((float)(qx + col) + 0.5f), dy = q0.y - ((float)(qy + row) + 0.5f);
+                float gx = q1.x * dx + q1.y * dy;
+                float gy = q1.y * dx + q1.z * dy;
+                float v_sigma = -q0.w * wf.x;
+                float hs = 0.5f * v_sigma;
+                acc[0] += v_sigma * gx;
+                acc[1] += v_sigma * gy;
+                acc[2] += hs * dx * dx;
+                acc[3] += v_sigma * dx * dy;
+                acc[4] += hs * dy * dy;
+                acc[5] += wf.x;
+                if (CG == D) {
+#pragma unroll
+                  for (int k = 0; k < D; ++k) acc[6 + k] += wf.y * sb.vcs[wv][pl][k];
+                } else {
+                  acc[6 + D - 1] += wf.y * sb.vcs[wv][pl][0];
                 }
               }
             }
           }
         }
-      }
-    }
-    __syncthreads();
-    // Flush the batch: pack non-zero slots so that 16 consecutive lanes add one Gaussian's 64-byte row.
-    {
-      bool nz = false;
-      if (tid < bsize) {
+        bool nzl = false;
 #pragma unroll
-        for (int k = 0; k < A; ++k) nz = nz || (sb.acc[tid * AP + k] != 0.f);
-      }
-      unsigned long long mask = __ballot(nz);
-      int cnt = __popcll(mask);
-      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-      __syncthreads();
-      int f = lane & 15;
-      for (int i0 = 0; i0 < cnt; i0 += 4) {
-        int gi = i0 + (lane >> 4);
-        if (gi < cnt && f < A) {
-          int sl = sb.list[wv][gi];
-          size_t g = (size_t)sb.id[sl];
-          atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+        for (int k = 0; k < A; ++k) {
+          float v = acc[k];
+          v += dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]
+          v += dpp_get<0x4E>(v);  // quad_perm [2,3,0,1]: all 4 lanes of the candidate hold its total
+          acc[k] = v;
+          nzl = nzl || (v != 0.f);
         }
+        if (part == 0) {
+#pragma unroll
+          for (int k = 0; k < A; ++k) sb.tot[wv][c2][k] = acc[k];
+        }
+        unsigned long long nzm = __ballot(nzl && part == 0);  // bit 4*c2 set <=> candidate c2 has a gradient
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // flush: 16 consecutive lanes add one candidate's 64-byte accumulator row
+        int f = lane & 15;
+        while (nzm) {
+          // up to 4 candidates per trip
+          int cand = -1;
+          unsigned long long mm = nzm;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            int bpos = mm ? (__ffsll((long long)mm) - 1) : -1;
+            if (mm) mm &= mm - 1;
+            if ((lane >> 4) == k) cand = bpos >> 2;
+          }
+          nzm = mm;
+          if (cand >= 0 && f < A) {
+            int t = sb.qlist[wv][cbase + cand];
+            size_t g = (size_t)sb.id[t];
+            atomicAdd(&vacc[g * 16 + f], sb.tot[wv][cand][f]);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
@@ -351,7 +415,9 @@ __global__ __launch_bounds__(256) void k_praster_bwd(
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float* __restrict__ vacc) {
-  __shared__ PStageB<D> sb;
+  // one LDS image, viewed through whichever variant (all channels / depth-only gradient) this tile runs
+  __shared__ __attribute__((aligned(16))) unsigned char sraw[sizeof(PStageB<D, D>) > sizeof(PStageB<D, 1>)
+                                                                 ? sizeof(PStageB<D, D>) : sizeof(PStageB<D, 1>)];
   __shared__ int s_final[4];
   int tile = ty0 * tile_w + blockIdx.x;
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
@@ -391,11 +457,11 @@ __global__ __launch_bounds__(256) void k_praster_bwd(
   if (rs >= re) return;
   int nb = (int)((re - rs + 255) / 256);
   if (D == 4 && !any_rgb)
-    praster_bwd_body<D, 1>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, txi, tyi, qx, qy, px, py, inside,
-                           bin_final, wave_final, T_final, vc, va);
+    praster_bwd_body<D, 1>(*reinterpret_cast<PStageB<D, 1>*>(sraw), Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid,
+                           txi, tyi, qx, qy, px, py, inside, bin_final, wave_final, T_final, vc, va);
   else
-    praster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, txi, tyi, qx, qy, px, py, inside,
-                           bin_final, wave_final, T_final, vc, va);
+    praster_bwd_body<D, D>(*reinterpret_cast<PStageB<D, D>*>(sraw), Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid,
+                           txi, tyi, qx, qy, px, py, inside, bin_final, wave_final, T_final, vc, va);
 }
 
 }  // namespace gsl

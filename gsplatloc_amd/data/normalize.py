@@ -1,0 +1,46 @@
+"""PCA normalisation of a frame pair (mirror of /root/reference/src/data/normalize.py:8-124)."""
+import torch
+from torch import Tensor
+
+
+@torch.no_grad()
+def align_principle_axes(point_cloud: Tensor) -> Tensor:
+    """normalize.py:8-50: median-centred PCA frame; eigenvectors by descending eigenvalue, first axis
+    flipped if the frame is left-handed.  Returns the 4x4 world->normalised transform."""
+    centroid = torch.median(point_cloud, dim=0).values
+    cov = torch.cov((point_cloud - centroid).t())
+    eigenvalues, eigenvectors = torch.linalg.eigh(cov)
+    eigenvectors = eigenvectors[:, eigenvalues.argsort(descending=True)]
+    if torch.det(eigenvectors) < 0:
+        eigenvectors[:, 0] *= -1
+    R = eigenvectors.t()
+    T = torch.eye(4, device=point_cloud.device, dtype=point_cloud.dtype)
+    T[:3, :3] = R
+    T[:3, 3] = -torch.mv(R, centroid)
+    return T
+
+
+@torch.no_grad()
+def transform_points(matrix: Tensor, points: Tensor) -> Tensor:
+    """normalize.py:53-72."""
+    return torch.addmm(matrix[:3, 3], points, matrix[:3, :3].t())
+
+
+@torch.no_grad()
+def transform_cameras(matrix: Tensor, c2w: Tensor):
+    """normalize.py:75-104: T @ c2w, rotation re-normalised by the norm of its first row (returned as the
+    scale factor; 1 for a rigid T)."""
+    transformed = torch.einsum("ki,nij->nkj", matrix, c2w)
+    scaling = torch.norm(transformed[:, 0, :3], p=2, dim=1, keepdim=True)
+    transformed[:, :3, :3] /= scaling.unsqueeze(-1)
+    return transformed, scaling
+
+
+@torch.no_grad()
+def normalize_pair(tar_points: Tensor, tar_pose: Tensor, src_points: Tensor, src_pose: Tensor):
+    """normalize.py:107-124 (normalize_2C): PCA frame of the target cloud applied to both clouds and poses."""
+    T = align_principle_axes(tar_points)
+    tar_pose_n, scale = transform_cameras(T, tar_pose.unsqueeze(0))
+    src_pose_n, _ = transform_cameras(T, src_pose.unsqueeze(0))
+    return (transform_points(T, tar_points), tar_pose_n.squeeze(0), transform_points(T, src_points),
+            src_pose_n.squeeze(0), scale)

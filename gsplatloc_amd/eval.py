@@ -1,0 +1,79 @@
+"""Sequence evaluation driver -- the role of /root/reference/src/GsplatLoc_eval.py + Runner.train +
+eval/logger.py:258-304 without W&B: track every consecutive frame pair of a room from the ground-truth pose
+of frame i, record the error of the minimum-loss iterate against frame i+1, and report
+ATE := RMSE of the translation errors, AAE := RMSE of the rotation errors (eval/utils.py:113-119), in the
+res.json layout of /root/reference/docs/res.json.
+
+    python -m gsplatloc_amd.eval --dataset Replica --rooms room0 --root /data/Replica --num-iters 200
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import time
+from typing import Dict, List, Optional
+
+import torch
+
+from .data import Parser
+from .graph_tracker import GraphTracker
+from .my_gsplat import TrackerConfig, init_gs_scales
+
+
+def rmse(values: List[float]) -> float:
+    """eval/utils.py:113-119."""
+    return math.sqrt(sum(v * v for v in values) / max(len(values), 1))
+
+
+def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[int] = 1998, verbose: bool = False) -> Dict:
+    """Runner.train (gs_trainer_total.py:45-282): frames 0..min(len, 1998)."""
+    cfg = TrackerConfig(max_steps=num_iters)
+    tracker = None
+    eTs, eRs, steps = [], [], []
+    t0 = time.perf_counter()
+    n = len(parser) if max_frames is None else min(len(parser), max_frames)
+    for i in range(n):
+        d = parser[i]
+        H, W = d.src_depth.shape[1:3]
+        if tracker is None or tracker.N != d.tar_points.shape[0]:
+            tracker = GraphTracker(d.tar_points.shape[0], W, H, cfg, device=d.tar_points.device)
+        tracker.load_frame(d.tar_points, d.colors, init_gs_scales(d.tar_points), d.src_depth, d.tar_c2w, d.src_c2w,
+                           parser.K)
+        res = tracker.run()
+        # early stop never fired before min_step: fall back to the last iterate's errors, as the reference would log inf
+        eTs.append(res.best_eT)
+        eRs.append(res.best_eR)
+        steps.append(res.steps)
+        if verbose:
+            print(f"frame {i}: steps {res.steps} loss {res.best_loss:.3e} eT {res.best_eT:.3e} eR {res.best_eR:.3e}")
+    dt = time.perf_counter() - t0
+    finite = [(a, b) for a, b in zip(eTs, eRs) if math.isfinite(a) and math.isfinite(b)]
+    return {"ATE": rmse([a for a, _ in finite]), "AAE": rmse([b for _, b in finite]), "frames": n,
+            "frames_with_result": len(finite), "mean_steps": sum(steps) / max(len(steps), 1),
+            "seconds": dt, "frames_per_s": n / dt if dt > 0 else None}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="GsplatLoc evaluation on the MI355X rasterizer")
+    ap.add_argument("--dataset", choices=["Replica", "TUM"], default="Replica")
+    ap.add_argument("--rooms", nargs="+", default=["room0"])
+    ap.add_argument("--root", required=True, help="dataset root (contains <room>/ for Replica, rgbd_dataset_* for TUM)")
+    ap.add_argument("--num-iters", type=int, default=2000)
+    ap.add_argument("--max-frames", type=int, default=1998)
+    ap.add_argument("--no-normalize", action="store_true")
+    ap.add_argument("--out", default="res.json")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args(argv)
+    out = {}
+    for room in a.rooms:
+        parser = Parser(a.dataset, room, normalize=not a.no_normalize, input_folder=a.root)
+        r = evaluate_room(parser, a.num_iters, a.max_frames, a.verbose)
+        out[room] = {"gsplatloc_amd": r}
+        print(room, json.dumps(r))
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=2)
+
+
+if __name__ == "__main__":
+    main()
