@@ -158,27 +158,49 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
         unsigned m = half ? mhi : mlo;
         while (__ballot(m != 0)) {
           if (m != 0) {
-            int bit = __ffs((int)m) - 1;
+            // two candidates per trip: both records are requested and both alphas evaluated before the
+            // transmittance updates are applied in list order (halves the dependent LDS round trips)
+            int bit0 = __ffs((int)m) - 1;
             m &= m - 1;
-            int t = sb.qlist[wv][c + half * 32 + bit];
-            float4 q0 = sb.s0[t], q1 = sb.s1[t];
-            float dx = q0.x - px, dy = q0.y - py;
-            float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
-            float alpha = fminf(GSL_ALPHA_MAX, q0.w * __expf(-sigma));
-            if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
-              float nT = T * (1.f - alpha);
+            bool two = m != 0;
+            int bit1 = two ? __ffs((int)m) - 1 : bit0;
+            m &= m - 1;
+            int t0 = sb.qlist[wv][c + half * 32 + bit0];
+            int t1 = sb.qlist[wv][c + half * 32 + bit1];
+            float4 p0 = sb.s0[t0], p1 = sb.s1[t0];
+            float4 u0 = sb.s0[t1], u1 = sb.s1[t1];
+            float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
+            float sg0 = 0.5f * (p1.x * dx0 * dx0 + p1.z * dy0 * dy0) + p1.y * dx0 * dy0;
+            float sg1 = 0.5f * (u1.x * dx1 * dx1 + u1.z * dy1 * dy1) + u1.y * dx1 * dy1;
+            float al0 = fminf(GSL_ALPHA_MAX, p0.w * __expf(-sg0));
+            float al1 = fminf(GSL_ALPHA_MAX, u0.w * __expf(-sg1));
+            if (sg0 >= 0.f && al0 >= GSL_ALPHA_MIN) {
+              float nT = T * (1.f - al0);
               if (nT <= GSL_T_STOP) {
-                done = true;
-                m = 0;
-                mhi = 0;
+                done = true; m = 0; mhi = 0; two = false;
               } else {
-                float vis = alpha * T;
+                float vis = al0 * T;
                 if (RGB) {
-                  float4 q2 = sb.s2[t];
+                  float4 q2 = sb.s2[t0];
                   pix[0] += q2.x * vis; pix[1] += q2.y * vis; pix[2] += q2.z * vis;
                 }
-                if (DEPTH) pix[D - 1] += q0.z * vis;
-                cur_idx = (int)bstart + t;
+                if (DEPTH) pix[D - 1] += p0.z * vis;
+                cur_idx = (int)bstart + t0;
+                T = nT;
+              }
+            }
+            if (two && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN) {
+              float nT = T * (1.f - al1);
+              if (nT <= GSL_T_STOP) {
+                done = true; m = 0; mhi = 0;
+              } else {
+                float vis = al1 * T;
+                if (RGB) {
+                  float4 q2 = sb.s2[t1];
+                  pix[0] += q2.x * vis; pix[1] += q2.y * vis; pix[2] += q2.z * vis;
+                }
+                if (DEPTH) pix[D - 1] += u0.z * vis;
+                cur_idx = (int)bstart + t1;
                 T = nT;
               }
             }
