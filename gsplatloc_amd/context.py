@@ -22,6 +22,9 @@ from ._lib import check, current_stream, load_library, ptr
 from .fused import _MODES, MAX_STRIP_TILES, _raster_fn, tile_n_bits
 
 
+TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
+
+
 class RenderContext:
     def __init__(self, N: int, width: int, height: int, render_mode: str = "RGB+ED", sh_degree: Optional[int] = 1,
                  K_sh: int = 4, device="cuda", eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10,
@@ -73,6 +76,8 @@ class RenderContext:
         else:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
         self.capacity = 0
+        self.tiny = False
+        self.trec = self.vcT = None
         self.keys = self.flatten_ids = None
         if capacity is not None:
             self._alloc_isects(int(capacity))
@@ -89,16 +94,32 @@ class RenderContext:
         self._project(means, quats, scales, opacities, colors, viewmat, K)
         n = int(self.n_is.item())
         self._alloc_isects(int(n * headroom) + 1024)
+        self._choose_backward()
         return n
 
+    def _choose_backward(self) -> None:
+        """Tiny-splat backward (per-splat 4x4 record slabs, no reduction, no atomics) when no splat reaches
+        more than 4x4 pixel centres (r_cull < 2 px) -- GsplatLoc's as-coded scales; otherwise the general
+        compositing backward.  GSLOC_TINY=0 disables."""
+        import os
+        r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
+        want = os.environ.get("GSLOC_TINY", "1") != "0" and r_max < TINY_RCULL_MAX
+        if want and self.trec is None:
+            self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
+            self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
+        self.tiny = want
+
     def check_capacity(self) -> int:
-        """Host sync: intersections of the last forward; raises if they did not fit."""
+        """Host sync: intersections of the last forward; raises if they did not fit (or if a splat outgrew the
+        tiny-splat backward chosen at calibration)."""
         n = int(self.n_is.item())
         if n > self.capacity:
             raise RuntimeError(f"intersection capacity exceeded ({n} > {self.capacity}); call calibrate() again")
+        if self.tiny and float(self.Q1[:, 3].max()) >= TINY_RCULL_MAX:
+            raise RuntimeError("a splat outgrew the tiny-splat backward (r_cull >= 2 px); call calibrate() again")
         return n
 
-    # ------------------------------------------------------------------ forward
+    # ------------------------------------------------------------------ stages (one C-ABI call each)
     def _project(self, means, quats, scales, opacities, colors, viewmat, K) -> None:
         check(self.lib.gsl_fused_project(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
@@ -107,37 +128,33 @@ class RenderContext:
             ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), ptr(self.comps), None, ptr(self.offs), ptr(self.n_is),
             ptr(self.ws), self.ws_bytes, current_stream()), "gsl_fused_project")
 
-    def forward(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
-                viewmat: Tensor, K: Tensor) -> Tuple[Tensor, Tensor]:
-        """Render into the context's buffers (valid until the next forward).  Inputs: contiguous fp32
-        device tensors; viewmat [4,4], K [3,3].  No allocation, no host sync."""
-        assert self.keys is not None, "call calibrate() (or pass capacity=) before forward()"
-        st = current_stream()
-        self._project(means, quats, scales, opacities, colors, viewmat, K)
+    def _bin(self) -> None:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
-                                     ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, st), "gsl_fused_bin")
-        check(_raster_fn(self.lib, 'fwd')(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
-                                            self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
-                                            ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
-                                            ptr(self.last_ids), st), "gsl_fused_raster_fwd")
-        self._inputs = (means, quats, scales, opacities, colors, viewmat, K)
-        return self.render, self.alphas
+                                     ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, current_stream()),
+              "gsl_fused_bin")
 
-    # ----------------------------------------------------------------- backward
-    def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None) -> Dict[str, Tensor]:
-        """vjp of the last forward.  Returns the context's gradient buffers: always ``viewmat``
-        ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors."""
-        assert self._inputs is not None, "forward() first"
-        full = self.full_grads if full is None else full
-        assert not full or self.full_grads, "context was built with full_grads=False"
+    def _raster_fwd(self) -> None:
+        check(_raster_fn(self.lib, 'fwd')(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
+                                          self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
+                                          ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
+                                          ptr(self.last_ids), current_stream()), "raster_fwd")
+
+    def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
+        common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,
+                  self.ty0, self.ty1, ptr(self.offs), ptr(self.flatten_ids), self.capacity, ptr(self.render),
+                  ptr(self.alphas), ptr(self.last_ids), ptr(v_render), ptr(v_alphas))
+        if self.tiny:
+            check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), current_stream()),
+                  "gsl_tiny_raster_bwd")
+            check(self.lib.gsl_tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W,
+                                           self.H, ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
+                  "gsl_tiny_gather")
+        else:
+            check(_raster_fn(self.lib, 'bwd')(*common, ptr(self.vacc), current_stream()), "raster_bwd")
+
+    def _project_bwd(self, full: bool) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
-        st = current_stream()
-        check(_raster_fn(self.lib, 'bwd')(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
-                                            self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
-                                            ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
-                                            ptr(self.last_ids), ptr(v_render), ptr(v_alphas), ptr(self.vacc), st),
-              "gsl_fused_raster_bwd")
         check(self.lib.gsl_fused_project_bwd(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
@@ -145,7 +162,28 @@ class RenderContext:
             ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
             ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
             ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
-            self.n_tiles, st), "gsl_fused_project_bwd")
+            self.n_tiles, current_stream()), "gsl_fused_project_bwd")
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
+                viewmat: Tensor, K: Tensor) -> Tuple[Tensor, Tensor]:
+        """Render into the context's buffers (valid until the next forward).  Inputs: contiguous fp32
+        device tensors; viewmat [4,4], K [3,3].  No allocation, no host sync."""
+        assert self.keys is not None, "call calibrate() (or pass capacity=) before forward()"
+        self._project(means, quats, scales, opacities, colors, viewmat, K)
+        self._bin()
+        self._raster_fwd()
+        self._inputs = (means, quats, scales, opacities, colors, viewmat, K)
+        return self.render, self.alphas
+
+    def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None) -> Dict[str, Tensor]:
+        """vjp of the last forward.  Returns the context's gradient buffers: always ``viewmat``
+        ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors."""
+        assert self._inputs is not None, "forward() first"
+        full = self.full_grads if full is None else full
+        assert not full or self.full_grads, "context was built with full_grads=False"
+        self._raster_bwd(v_render, v_alphas)
+        self._project_bwd(full)
         out = {"viewmat": self.v_viewmat}
         if full:
             out.update(means=self.v_means, quats=self.v_quats, scales=self.v_scales, opacities=self.v_opacities,
@@ -180,10 +218,7 @@ class _CtxRender(torch.autograd.Function):
 
 def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, full: bool, steps: int = 20) -> Dict:
     """Average duration (ms) of each of the five stage calls of one iteration, measured with HIP events
-    recorded on the launch stream around every C-ABI call (dev/bench tool; same launches as
-    forward()/backward())."""
-    means, quats, scales, opacities, colors, viewmat, K = inputs
-    lib = rc.lib
+    recorded on the launch stream around every C-ABI call (same launches as forward()/backward())."""
     names = ["project_fwd", "bin", "raster_fwd", "raster_bwd", "project_bwd"]
     acc = {n: 0.0 for n in names}
 
@@ -193,30 +228,17 @@ def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, f
         return e
 
     for it in range(steps + 2):
-        st = current_stream()
         marks = [ev()]
-        rc._project(means, quats, scales, opacities, colors, viewmat, K)
+        rc._project(*inputs)
         marks.append(ev())
-        check(lib.gsl_fused_bin(ptr(rc.Q0), ptr(rc.radii), rc.N, rc.tw, rc.th, rc.ty0, rc.ty1,
-                                tile_n_bits(rc.n_tiles), ptr(rc.offs), rc.capacity, ptr(rc.keys),
-                                ptr(rc.flatten_ids), None, ptr(rc.ws), rc.ws_bytes, st), "gsl_fused_bin")
+        rc._bin()
         marks.append(ev())
-        check(_raster_fn(lib, 'fwd')(ptr(rc.Q0), ptr(rc.Q1), ptr(rc.Q2), rc.D, int(rc.ed), rc.W, rc.H, rc.tw,
-                                       rc.th, rc.ty0, rc.ty1, ptr(rc.offs), ptr(rc.flatten_ids), rc.capacity,
-                                       ptr(rc.render), ptr(rc.alphas), ptr(rc.last_ids), st), "gsl_fused_raster_fwd")
+        rc._raster_fwd()
+        rc._inputs = tuple(inputs)
         marks.append(ev())
-        check(_raster_fn(lib, 'bwd')(ptr(rc.Q0), ptr(rc.Q1), ptr(rc.Q2), rc.D, int(rc.ed), rc.W, rc.H, rc.tw,
-                                       rc.th, rc.ty0, rc.ty1, ptr(rc.offs), ptr(rc.flatten_ids), rc.capacity,
-                                       ptr(rc.render), ptr(rc.alphas), ptr(rc.last_ids), ptr(v_render),
-                                       ptr(v_alphas), ptr(rc.vacc), st), "gsl_fused_raster_bwd")
+        rc._raster_bwd(v_render, v_alphas)
         marks.append(ev())
-        check(lib.gsl_fused_project_bwd(
-            ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rc.rgb else None, rc.sh_degree,
-            rc.K_sh, ptr(viewmat), ptr(K), rc.N, rc.W, rc.H, rc.eps2d, int(rc.antialiased), rc.D, ptr(rc.radii),
-            ptr(rc.Q1), ptr(rc.comps), ptr(rc.vacc), ptr(rc.v_means) if full else None,
-            ptr(rc.v_quats) if full else None, ptr(rc.v_scales) if full else None,
-            ptr(rc.v_opacities) if full else None, ptr(rc.v_colors) if (full and rc.rgb) else None,
-            ptr(rc.v_viewmat), ptr(rc.ws), rc.ws_bytes, rc.n_tiles, st), "gsl_fused_project_bwd")
+        rc._project_bwd(full)
         marks.append(ev())
         torch.cuda.synchronize()
         if it >= 2:

@@ -486,6 +486,255 @@ __global__ __launch_bounds__(256) void k_praster_bwd(
                            txi, tyi, qx, qy, px, py, inside, bin_final, wave_final, T_final, vc, va);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// "Tiny splat" backward (every r_cull < 2 px: the alpha >= 1/255 disc covers at most 4x4 pixel centres --
+// the situation of GsplatLoc's as-coded kNN scales, where every splat is the 0.3 px^2 blur).
+// Pass 1 (this kernel, lane = pixel): the back-to-front walk of the px scheme; per composited
+// (pixel, splat) it stores  (w, fac) = (vis * v_alpha [0 when alpha is clamped], alpha * T)  into the
+// splat's own 4x4 slab  trec[g][row - r0][col - c0]  (plain 8-byte stores, no atomics, no reduction), and
+// every pixel leaves its (expected-depth-chained) upstream gradient in vcT[H,W,D].
+// Pass 2 lives in the per-Gaussian projection backward (fused.hip, k_fproject_bwd<.., TINY>): it reads the
+// slab of its Gaussian, rebuilds dx, dy from the Gaussian's own record and sums the 16 slots.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tiny_origin(float centre, float r) {  // first pixel index within r of centre
+  return (int)ceilf(centre - r - 0.5f);
+}
+
+template <int D>
+struct TStage {
+  float4 s0[256];
+  float4 s1[256];
+  float4 s2[(D >= 3) ? 256 : 1];
+  uint16_t qlist[4][256];
+  int qcnt[4][4];
+  int32_t id[256];
+};
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_tiny_bwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+    float2* __restrict__ trec, float* __restrict__ vcT) {
+  constexpr bool RGB = D >= 3;
+  constexpr bool DEPTH = (D == 1) || (D == 4);
+  __shared__ TStage<D> sb;
+  __shared__ int s_final[4];
+  int tile = ty0 * tile_w + blockIdx.x;
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+  size_t pid = inside ? ((size_t)i * W + j) : 0;
+  float Aimg = inside ? alphas[pid] : 0.f;
+  float T_final = 1.f - Aimg;
+  int bin_final = inside ? last_ids[pid] : -1;
+  float vc[D];
+  float va = inside ? v_alphas[pid] : 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
+  if (ED && inside) {
+    float dn = render[pid * D + (D - 1)];
+    float vd = vc[D - 1];
+    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
+    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
+  }
+  if (inside) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) vcT[pid * D + k] = vc[k];
+  }
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs >= re) return;
+  int wave_final = bin_final;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
+  if (lane == 0) s_final[wv] = wave_final;
+  __syncthreads();
+  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
+  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (rs >= re) return;
+  int nb = (int)((re - rs + 255) / 256);
+  float T = T_final;
+  float Bp = -T_final * va;
+
+  for (int b = 0; b < nb; ++b) {
+    long long bend = re - 1 - (long long)b * 256;
+    int bsize = (int)min((long long)256, bend + 1 - rs);
+    __syncthreads();
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (tid < bsize) {
+      int g = flatten_ids[bend - tid];
+      sb.id[tid] = g;
+      r0 = Q0[g];
+      r1 = Q1[g];
+      sb.s0[tid] = r0;
+      sb.s1[tid] = r1;
+      if (RGB) sb.s2[tid] = Q2[g];
+    }
+    int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
+    int t_first = (int)max((long long)0, bend - (long long)wave_final);
+    int t_lane = inside ? (int)max((long long)0, bend - (long long)bin_final) : 1 << 30;
+    for (int c = 0; c < n; c += 64) {
+      int e = c + lane;
+      int lox = 1, hix = 0, loy = 1, hiy = 0;
+      if (e < n) {
+        int t = sb.qlist[wv][e];
+        if (t >= t_first) {
+          float4 a0 = sb.s0[t];
+          float r = sb.s1[t].w;
+          box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
+          box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
+        }
+      }
+      unsigned mlo, mhi;
+      pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        unsigned m = half ? mhi : mlo;
+        while (__ballot(m != 0)) {
+          if (m != 0) {
+            int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            int t = sb.qlist[wv][c + half * 32 + bit];
+            if (t >= t_lane) {
+              float4 q0 = sb.s0[t], q1 = sb.s1[t];
+              float dx = q0.x - px, dy = q0.y - py;
+              float gx = q1.x * dx + q1.y * dy;
+              float gy = q1.y * dx + q1.z * dy;
+              float sigma = 0.5f * (dx * gx + dy * gy);
+              float vis = __expf(-sigma);
+              float opv = q0.w * vis;
+              float alpha = fminf(GSL_ALPHA_MAX, opv);
+              if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
+                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                T *= ra;
+                float fac = alpha * T;
+                float cdot = 0.f;
+                if (RGB) {
+                  float4 q2 = sb.s2[t];
+                  cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
+                }
+                if (DEPTH) cdot += q0.z * vc[D - 1];
+                float v_alpha = T * cdot - ra * Bp;
+                Bp += fac * cdot;
+                float w = (opv <= GSL_ALPHA_MAX) ? vis * v_alpha : 0.f;
+                int cc = j - tiny_origin(q0.x, q1.w), rr = i - tiny_origin(q0.y, q1.w);
+                if ((unsigned)cc < 4u && (unsigned)rr < 4u)
+                  trec[(size_t)sb.id[t] * 16 + rr * 4 + cc] = make_float2(w, fac);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Pass 2: 16 lanes (one DPP row) per Gaussian, one lane per slab slot; row reduction; the Gaussian's
+// 64-byte gradient row is written whole (plain stores) and the slab is cleared.
+template <int D>
+__global__ __launch_bounds__(256) void k_tiny_gather(const float4* __restrict__ Q0, const float4* __restrict__ Q1,
+                                                     const int32_t* __restrict__ radii, int N, int W, int H,
+                                                     float2* __restrict__ trec, const float* __restrict__ vcT,
+                                                     float4* __restrict__ vacc) {
+  constexpr int A = 6 + D;
+  int gid = (blockIdx.x * 256 + threadIdx.x) >> 4, s = threadIdx.x & 15;
+  bool live = gid < N && radii[gid] > 0;
+  float v[A];
+#pragma unroll
+  for (int k = 0; k < A; ++k) v[k] = 0.f;
+  if (live) {
+    float2 wf = trec[(size_t)gid * 16 + s];
+    if (wf.x != 0.f || wf.y != 0.f) {
+      trec[(size_t)gid * 16 + s] = make_float2(0.f, 0.f);
+      float4 q0 = Q0[gid], qc = Q1[gid];
+      int pcol = tiny_origin(q0.x, qc.w) + (s & 3), prow = tiny_origin(q0.y, qc.w) + (s >> 2);
+      float dx = q0.x - ((float)pcol + 0.5f), dy = q0.y - ((float)prow + 0.5f);
+      float gx = qc.x * dx + qc.y * dy, gy = qc.y * dx + qc.z * dy;
+      float v_sigma = -q0.w * wf.x, hs = 0.5f * v_sigma;
+      v[0] = v_sigma * gx; v[1] = v_sigma * gy;
+      v[2] = hs * dx * dx; v[3] = v_sigma * dx * dy; v[4] = hs * dy * dy;
+      v[5] = wf.x;
+      if (wf.y != 0.f && (unsigned)pcol < (unsigned)W && (unsigned)prow < (unsigned)H) {
+        size_t pid = (size_t)prow * W + pcol;
+#pragma unroll
+        for (int k = 0; k < D; ++k) v[6 + k] = wf.y * vcT[pid * D + k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < A; ++k) {
+    float x = v[k];
+    x += dpp_get<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_get<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_get<0x141>(x);  // row_half_mirror
+    x += dpp_get<0x140>(x);  // row_mirror: every lane of the 16-lane row holds the Gaussian's total
+    v[k] = x;
+  }
+  if (live) {
+    float pad[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pad[k] = (k < A) ? v[k] : 0.f;
+    if (s == 0) vacc[4 * (size_t)gid] = make_float4(pad[0], pad[1], pad[2], pad[3]);
+    if (s == 1) vacc[4 * (size_t)gid + 1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
+    if (s == 2) vacc[4 * (size_t)gid + 2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
+  }
+}
+
+}  // namespace gsl
+
+extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                                   int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                                   const int32_t* flatten_ids, int64_t capacity, const float* render,
+                                   const float* alphas, const int32_t* last_ids, const float* v_render,
+                                   const float* v_alphas, float* trec, float* vcT, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas || !trec || !vcT)
+    return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (ty0 == ty1) return GSL_OK;
+  if (capacity > 0 && (!Q0 || !Q1 || !flatten_ids || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (ty1 - ty0) * tile_w;
+#define CALL_TB(DD, EE)                                                                                      \
+  hipLaunchKernelGGL((gsl::k_tiny_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,            \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas,         \
+                     (float2*)trec, vcT)
+  if (channels == 1) { if (ed) CALL_TB(1, true); else CALL_TB(1, false); }
+  else if (channels == 3) { CALL_TB(3, false); }
+  else if (channels == 4) { if (ed) CALL_TB(4, true); else CALL_TB(4, false); }
+  else return GSL_ERR_BAD_ARG;
+#undef CALL_TB
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+extern "C" int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
+                               int height, float* trec, const float* vcT, float* vacc, void* stream) {
+  if (N < 0 || width <= 0 || height <= 0) return GSL_ERR_BAD_ARG;
+  if (channels != 1 && channels != 3 && channels != 4) return GSL_ERR_BAD_ARG;
+  if (N == 0) return GSL_OK;
+  if (!Q0 || !Q1 || !radii || !trec || !vcT || !vacc) return GSL_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned grid = (unsigned)(((size_t)N * 16 + 255) / 256);
+#define CALL_TG(DD)                                                                                              \
+  hipLaunchKernelGGL((gsl::k_tiny_gather<DD>), dim3(grid), dim3(256), 0, st, (const float4*)Q0, (const float4*)Q1, \
+                     radii, N, width, height, (float2*)trec, vcT, (float4*)vacc)
+  if (channels == 1) CALL_TG(1); else if (channels == 3) CALL_TG(3); else CALL_TG(4);
+#undef CALL_TG
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+namespace gsl {
 }  // namespace gsl
 
 #define GSL_P_DISPATCH(D, ED, CALL)                                \

@@ -187,6 +187,21 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
+/* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4
+ * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_*_raster_bwd: instead of
+ * reducing and accumulating gradient rows it stores per (splat, pixel) records into trec[N][16][2] (zero on
+ * entry) and the chained upstream gradient of every pixel into vcT[H,W,channels]; gsl_tiny_gather then sums
+ * each Gaussian's 4x4 slab into its vacc row (overwritten, same layout as above) and clears the slab.
+ * gsl_fused_project_bwd follows unchanged. */
+int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                        int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                        const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                        const float* render, const float* alphas, const int32_t* last_ids,
+                        const float* v_render, const float* v_alphas, float* trec, float* vcT,
+                        void* stream);
+int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
+                    int height, float* trec, const float* vcT, float* vacc, void* stream);
+
 /* Per-pixel-mask compositing (csrc/raster_px.hip): same contract and arguments as
  * gsl_fused_raster_fwd / gsl_fused_raster_bwd, a different kernel organisation: every lane walks the
  * candidate list of its own pixel, which suits the pixel-sized splats of the pose tracker. */

@@ -346,3 +346,39 @@ def test_fused_tile_strip_matches_full_render():
         assert float(r[:y0].abs().max() if y0 else 0) == 0 and float(r[y1:].abs().max() if y1 < H else 0) == 0
         g_sum += g
     assert rel_inf(g_sum, g_full) < 1e-5
+
+
+@pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB+ED", False)])
+def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
+    """RenderContext picks the tiny-splat backward (4x4 record slabs, no atomics) when r_cull < 2 px; its
+    gradients must agree with the general compositing backward on the same render."""
+    A = _gpu()
+    from gsplatloc_amd.context import RenderContext
+    W, H, N = 200, 136, 30000
+    sc = _scene32(N, W, H, sigma_px=0.0)   # scales -> 0: every splat is the 0.3 px^2 blur (radius 2)
+    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+    ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
+    V = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
+    K = sc["K"].to(DEV).contiguous()
+    gen = torch.Generator().manual_seed(3)
+    D = 4 if mode == "RGB+ED" else 1
+    v = torch.randn(H, W, D, generator=gen).to(DEV)
+    if mode == "RGB+ED" and not full:
+        v[..., :3] = 0  # the tracker's situation: only the depth channel carries a gradient
+    va = torch.randn(H, W, 1, generator=gen).to(DEV)
+    out = {}
+    for tiny in ("1", "0"):
+        monkeypatch.setenv("GSLOC_TINY", tiny)
+        rc = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=DEV, full_grads=full)
+        rc.calibrate(*ins, V, K)
+        assert rc.tiny == (tiny == "1")
+        for _ in range(2):  # twice: the slabs / rows must come back clean
+            rc.forward(*ins, V, K)
+            g = rc.backward(v, va, full=full)
+        rc.check_capacity()
+        out[tiny] = {k: (t.clone() if t is not None else None) for k, t in g.items()}
+    assert rel_inf(out["1"]["viewmat"], out["0"]["viewmat"]) < 2e-5
+    if full:
+        for k in ("means", "scales", "opacities", "colors"):
+            scale = float(out["0"][k].abs().max())
+            mostly_close(out["1"][k], out["0"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
