@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tracker", action="store_true", help="skip the pose-opt iterations/s side measurement")
+    ap.add_argument("--no-variants", action="store_true", help="skip the side measurements of the other workload variants")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank path with every rank on cuda:0 and a gloo (host) all-reduce")
@@ -94,6 +95,48 @@ def cpu_baseline(args):
     return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"oracle/gsplat_oracle.py fp32, N={n} on {w}x{h} (N/16, W/4 x H/4 of the workload), "
                       f"fwd+bwd, best of 2 after warm-up, {dt:.2f} s/step"}
+
+
+def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
+    """Side measurement: the same step on another variant of the workload (graph replay, all gradients)."""
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev, order=order)
+    viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    K = sc["K"].contiguous()
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+    n_is = ctx.calibrate(*inp)
+    g = torch.Generator().manual_seed(1)
+    v = torch.zeros(H, W, 4)
+    v[..., 3] = torch.randn(H, W, generator=g)
+    v = v.to(dev)
+    va = torch.zeros(H, W, 1, device=dev)
+
+    def step():
+        ctx.forward(*inp)
+        ctx.backward(v, va, full=True)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    ctx.check_capacity()
+    return {"sigma_px": sigma_px, "order": order, "intersections_per_gaussian": n_is / N, "ms_per_step": dt * 1e3,
+            "gaussians_per_s": N / dt, "backward": "tiny-splat slabs" if ctx.tiny else "wave reduce-scatter"}
 
 
 def pose_opt_rate(dev):
@@ -284,6 +327,11 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not args.no_tracker:
             out["pose_opt"] = pose_opt_rate(dev)
+        if world == 1 and not args.no_variants:
+            # same N and image, the other synthetic inputs of SURVEY.md 8(d): sigma_px -> 0 is the regime of the
+            # reference's as-coded kNN scales; "raster" is the Gaussian order of a back-projected depth frame
+            out["variants"] = [variant_rate(dev, N, W, H, s_, o_) for s_, o_ in
+                               ((1.0, "raster"), (0.0, "random"), (0.0, "raster"))]
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
