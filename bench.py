@@ -42,12 +42,21 @@ def parse():
     ap.add_argument("--order", choices=["random", "raster"], default="random")
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-div", type=int, default=2,
+                    help="cpu_baseline sample: N/div^2 Gaussians on a (W/div)x(H/div) image (same density)")
     ap.add_argument("--no-tracker", action="store_true", help="skip the pose-opt iterations/s side measurement")
     ap.add_argument("--no-variants", action="store_true", help="skip the side measurements of the other workload variants")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank path with every rank on cuda:0 and a gloo (host) all-reduce")
     return ap.parse_args()
+
+
+def trace(msg):
+    """GSLOC_BENCH_TRACE=1: synchronise and print a phase marker (to localise an asynchronous GPU fault)."""
+    if os.environ.get("GSLOC_BENCH_TRACE"):
+        torch.cuda.synchronize()
+        print(f"[trace rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
 
 def algorithmic_bytes(N, I, P, D, n_tiles, full):
@@ -64,37 +73,59 @@ def algorithmic_bytes(N, I, P, D, n_tiles, full):
     }
 
 
+STAGE_KERNELS = {  # stage timer -> kernels it brackets (names as rocprofv3 prints them, template arguments dropped)
+    "project_fwd": ("k_fproject<",), "bin": ("k_ftile_scan", "k_fscatter", "k_tile_sort"),
+    "raster_fwd": ("k_praster_fwd", "k_fraster_fwd"), "raster_bwd": ("k_fraster_bwd", "k_praster_bwd", "k_tiny_bwd", "k_tiny_gather"),
+    "project_bwd": ("k_fproject_bwd", "k_freduce_viewmat"),
+}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernels from the committed PMC passes of this same command
+    (profiles/r01_pmc_traffic.json, made by scripts/pmc_summary.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs; counters cannot be read from inside the process).  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    tot = [v["hbm_bytes"] for k, v in ks.items() if any(k.startswith(p) for p in STAGE_KERNELS.get(stage, ()))]
+    return sum(tot) if tot else None
+
+
 def cpu_baseline(args):
     """The CPU oracle (pure PyTorch restatement, the 'port') timed on the host cores on a bounded
-    sample of the same workload: N/16 Gaussians on a (W/4)x(H/4) image, same sigma_px and density
-    (SURVEY.md 8d).  Threads = min(host cores, 16): a 1-GPU box exposes a 16-core share."""
+    sample of the same workload: N/div^2 Gaussians on a (W/div)x(H/div) image, same sigma_px and density
+    (div = 2 is ~10 s of CPU work).  Threads = min(host cores, 16): a 1-GPU box exposes a
+    16-core share."""
     from oracle import gsplat_oracle as G
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
 
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    n, w, h = args.n // 16, args.width // 4, args.height // 4
-    sc = random_scene(n, w, h, sigma_px=args.sigma_px)
+    div = max(1, args.cpu_sample_div)
     V = torch.linalg.inv(perturbed_pose())[None]
-    g = torch.Generator().manual_seed(1)
-    vd = torch.randn(1, h, w, generator=g)
 
-    def step():
-        ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "sh")]
-        Vg = V.clone().requires_grad_()
-        rc, ra, _ = G.rasterization(*ins, Vg, sc["K"][None], w, h, sh_degree=1, render_mode="RGB+ED")
-        (rc[..., 3] * vd).sum().backward()
+    def make_step(d):
+        n, w, h = args.n // (d * d), args.width // d, args.height // d
+        sc = random_scene(n, w, h, sigma_px=args.sigma_px)
+        g = torch.Generator().manual_seed(1)
+        vd = torch.randn(1, h, w, generator=g)
 
+        def step():
+            ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "sh")]
+            Vg = V.clone().requires_grad_()
+            rc, ra, _ = G.rasterization(*ins, Vg, sc["K"][None], w, h, sh_degree=1, render_mode="RGB+ED")
+            (rc[..., 3] * vd).sum().backward()
+        return step, n, w, h
+
+    make_step(div * 4)[0]()  # warm-up on a small sample (thread pool, allocator)
+    step, n, w, h = make_step(div)
+    t = time.perf_counter()
     step()
-    ts = []
-    for _ in range(2):
-        t = time.perf_counter()
-        step()
-        ts.append(time.perf_counter() - t)
-    dt = sorted(ts)[0]
+    dt = time.perf_counter() - t
     return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/gsplat_oracle.py fp32, N={n} on {w}x{h} (N/16, W/4 x H/4 of the workload), "
-                      f"fwd+bwd, best of 2 after warm-up, {dt:.2f} s/step"}
+            "sample": f"oracle/gsplat_oracle.py fp32, N={n} on {w}x{h} (N/{div * div}, W/{div} x H/{div} of the workload, "
+                      f"same splat density), one fwd+bwd step after a small warm-up, {dt:.2f} s"}
 
 
 def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
@@ -218,8 +249,10 @@ def main():
             sc[k] = sc[k][idx].contiguous()
         n_local = int(idx.numel())
         del cal
+        trace(f"strip rows {rows}, {n_local} local Gaussians")
     ctx = RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full)
     n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+    trace(f"calibrated, {n_isects} intersections")
     g = torch.Generator().manual_seed(1)
     v_render = torch.zeros(H, W, 4)
     v_render[..., 3] = torch.randn(H, W, generator=g)
@@ -228,34 +261,40 @@ def main():
     pose_grad = torch.zeros(16, device=dev)
     args_in = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
 
-    def step():
+    def render_step():
         ctx.forward(*args_in)
         grads = ctx.backward(v_render, v_alphas, full=full)
-        if dist is not None:
-            if args.rehearse_on_one_gpu:
-                host = grads["viewmat"].reshape(16).cpu()
-                dist.all_reduce(host)
-                pose_grad.copy_(host)
-            else:
-                pose_grad.copy_(grads["viewmat"].reshape(16))
-                dist.all_reduce(pose_grad)
+        pose_grad.copy_(grads["viewmat"].reshape(16))
 
     graph = None
     side = torch.cuda.Stream()
-    if not args.no_graph and dist is None:
-        # one iteration = a fixed sequence of 10 launches: replay it as a single HIP graph
+    if not args.no_graph:
+        # one iteration = a fixed sequence of ~10 launches: replay it as a single HIP graph (per rank)
         with torch.cuda.stream(side):
             for _ in range(2):
-                step()
+                render_step()
             torch.cuda.synchronize()
+            trace("eager steps done")
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                step()
+                render_step()
         torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+        trace("graph captured")
+    render = graph.replay if graph is not None else render_step
+
+    def run():
+        render()
+        if dist is not None:  # THE collective of the path: 12 pose-gradient entries (+4 spare) per step
+            if args.rehearse_on_one_gpu:
+                host = pose_grad.cpu()
+                dist.all_reduce(host)
+                pose_grad.copy_(host)
+            else:
+                dist.all_reduce(pose_grad)
 
     for _ in range(args.warmup):
         run()
+        trace("warm-up step")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -274,6 +313,7 @@ def main():
         dt = float(t.item())
     n_total = ctx.check_capacity()
     ms = dt / args.steps * 1e3
+    trace("timed steps done")
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps, second pass -------
     stage_ms = {}
@@ -313,7 +353,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                "frac": (achieved / 8000.0) if achieved else None,
+                "traffic": pmc_traffic(dom) if (world == 1 and args.sigma_px == 1.0 and args.order == "random" and N == 1_000_000) else None,
                 "algorithmic_bytes_per_launch": bytes_stage[dom], "avg_launch_ms": dom_ms,
                 "whole_step": {"algorithmic_bytes": sum(bytes_stage.values()),
                                "achieved_GBps": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9,

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/<tag>_pmc_traffic.json.
+
+    python scripts/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+
+Per kernel: mean bytes per launch.  FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE
+counts a 128-B request as 64 B, so fetch bytes are doubled (MI355X_MICROARCH.md, "HBM [CDNA4]"); the guide
+calibrates that factor on wide streaming reads only, so for the 16-B gathers of the compositing kernels the
+doubled figure is an upper estimate.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0]
+            name = name.replace("void ", "").replace("gsl::", "")
+            acc[name].append(float(row["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("k_"):
+            continue
+        fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * 2.0
+        wb = write.get(k, (0.0, 0))[0] * 1024.0
+        out[k] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
+                  "launches": max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])}
+    json.dump({"note": "mean per launch; fetch = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write = WRITE_SIZE KiB x 1024",
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:48s} fetch {v['fetch_bytes']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB  x{v['launches']}")
+
+
+if __name__ == "__main__":
+    main()
