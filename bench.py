@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--order", choices=["random", "raster"], default="random")
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-div", type=int, default=2,
+    ap.add_argument("--cpu-sample-div", type=int, default=3,
                     help="cpu_baseline sample: N/div^2 Gaussians on a (W/div)x(H/div) image (same density)")
     ap.add_argument("--no-tracker", action="store_true", help="skip the pose-opt iterations/s side measurement")
     ap.add_argument("--no-variants", action="store_true", help="skip the side measurements of the other workload variants")
@@ -95,7 +95,7 @@ def pmc_traffic(stage):
 def cpu_baseline(args):
     """The CPU oracle (pure PyTorch restatement, the 'port') timed on the host cores on a bounded
     sample of the same workload: N/div^2 Gaussians on a (W/div)x(H/div) image, same sigma_px and density
-    (div = 2 is ~10 s of CPU work).  Threads = min(host cores, 16): a 1-GPU box exposes a
+    (div = 3 is 10-20 s of CPU work in total).  Threads = min(host cores, 16): a 1-GPU box exposes a
     16-core share."""
     from oracle import gsplat_oracle as G
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
@@ -118,14 +118,17 @@ def cpu_baseline(args):
             (rc[..., 3] * vd).sum().backward()
         return step, n, w, h
 
-    make_step(div * 4)[0]()  # warm-up on a small sample (thread pool, allocator)
     step, n, w, h = make_step(div)
-    t = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t
+    step()  # warm-up at the same size (the first pass pays for allocator growth: ~3x slower)
+    ts = []
+    for _ in range(2):
+        t = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t)
+    dt = min(ts)
     return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
             "sample": f"oracle/gsplat_oracle.py fp32, N={n} on {w}x{h} (N/{div * div}, W/{div} x H/{div} of the workload, "
-                      f"same splat density), one fwd+bwd step after a small warm-up, {dt:.2f} s"}
+                      f"same splat density), fwd+bwd, best of 2 after one warm-up step, {dt:.2f} s/step"}
 
 
 def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
@@ -261,36 +264,34 @@ def main():
     pose_grad = torch.zeros(16, device=dev)
     args_in = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
 
-    def render_step():
+    def step():
         ctx.forward(*args_in)
         grads = ctx.backward(v_render, v_alphas, full=full)
-        pose_grad.copy_(grads["viewmat"].reshape(16))
+        if dist is not None:
+            if args.rehearse_on_one_gpu:
+                host = grads["viewmat"].reshape(16).cpu()
+                dist.all_reduce(host)
+                pose_grad.copy_(host)
+            else:
+                pose_grad.copy_(grads["viewmat"].reshape(16))
+                dist.all_reduce(pose_grad)  # THE collective of the path: 12 pose-gradient entries (+4 spare)
 
     graph = None
     side = torch.cuda.Stream()
-    if not args.no_graph:
-        # one iteration = a fixed sequence of ~10 launches: replay it as a single HIP graph (per rank)
+    if not args.no_graph and dist is None:
+        # one iteration = a fixed sequence of 10 launches: replay it as a single HIP graph.  (N > 1 launches
+        # eagerly: a per-rank graph followed by the collective faulted in the one-GPU rehearsal)
         with torch.cuda.stream(side):
             for _ in range(2):
-                render_step()
+                step()
             torch.cuda.synchronize()
             trace("eager steps done")
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                render_step()
+                step()
         torch.cuda.synchronize()
         trace("graph captured")
-    render = graph.replay if graph is not None else render_step
-
-    def run():
-        render()
-        if dist is not None:  # THE collective of the path: 12 pose-gradient entries (+4 spare) per step
-            if args.rehearse_on_one_gpu:
-                host = pose_grad.cpu()
-                dist.all_reduce(host)
-                pose_grad.copy_(host)
-            else:
-                dist.all_reduce(pose_grad)
+    run = graph.replay if graph is not None else step
 
     for _ in range(args.warmup):
         run()
