@@ -35,6 +35,17 @@ class RGBDFrame:
     K: np.ndarray  # [3,3]
     pose: np.ndarray  # [4,4] camera-to-world
 
+    @property
+    def points(self) -> np.ndarray:
+        """[H*W,3] camera-frame back-projection of every pixel (RGBDImage.points, Image.py:111-118); pixels
+        without depth stay at the origin, as in the reference -- consumers filter z > 0."""
+        h, w = self.depth.shape
+        v, u = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+        z = self.depth.astype(np.float64)
+        x = (u - self.K[0, 2]) / self.K[0, 0] * z
+        y = (v - self.K[1, 2]) / self.K[1, 1] * z
+        return np.stack([x, y, z], axis=-1).reshape(-1, 3)
+
 
 class BaseDataset(Sequence):
     """dataset.py:17-76: camera config (json/yaml), optional crop_edge, K."""
