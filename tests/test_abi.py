@@ -17,6 +17,19 @@ def test_header_and_binding_agree(repo_root):
     assert _declared(repo_root) == _lib.exported_symbols()
 
 
+def test_headers_are_plain_c(repo_root):
+    """The boundary is a C ABI: both headers must compile as C99 without any HIP / C++ / torch type."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    for h in ("gsloc_hip.h", "gsloc_icp.h"):
+        res = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                              os.path.join(repo_root, "include", h)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+
+
 def test_library_exports_every_symbol(repo_root):
     if not os.path.exists(_lib.library_path()):
         _lib.build_library()
