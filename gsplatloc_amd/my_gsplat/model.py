@@ -1,5 +1,20 @@
-"""Mirror of /root/reference/src/my_gsplat/model.py (minus the nerfview viewer callback)."""
+"""Pose parameters and Gaussian model of the tracker, with the public interface of
+/root/reference/src/my_gsplat/model.py (CameraConfig :18-23, CameraOptModule_quat_tans :27-116, GsConfig
+:119-133, GSModel :136-215): same constructor arguments, attribute names and results, so the reference's
+trainer code runs on it unchanged.  The nerfview viewer hook is not part of the path and is left out.
+
+Differences that do not change results:
+* both pose parameters live in ONE Adam with two parameter groups (own learning rate and L2 weight decay
+  each) instead of two Adam objects -- Adam is element-wise, so the updates are identical, and
+  ``optimizers`` stays a list for the schedulers built over it (gs_trainer_total.py:65-72);
+* the activated opacities and the concatenated SH coefficients are constants of a frame: GSModel builds
+  them once and rebuilds only if ``opacities`` / ``sh0`` / ``shN`` were replaced or modified in place
+  (the reference re-runs sigmoid and cat on every iteration).
+"""
+from __future__ import annotations
+
 from dataclasses import dataclass
+from typing import List, Optional, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -12,103 +27,128 @@ from .utils import rgb_to_sh
 
 
 @dataclass(frozen=True)
-class CameraConfig:  # model.py:18-23
+class CameraConfig:
     trans_lr: float = 1e-3
     quat_lr: float = 5 * 1e-4
     quat_opt_reg: float = 1e-3
     trans_opt_reg: float = 1e-3
 
 
+def _split_pose(pose: Tensor) -> Tuple[Tensor, Tensor]:
+    """4x4 camera-to-world -> (wxyz quaternion [4], translation [3]), detached copies."""
+    if not (torch.is_tensor(pose) and pose.shape == (4, 4)):
+        raise ValueError("fake new pose")
+    pose = pose.detach()
+    return rotation_matrix_to_quaternion(pose[:3, :3].contiguous()), pose[:3, 3].clone()
+
+
 class CameraOptModule_quat_tans(nn.Module):
-    """model.py:27-116: pose = (wxyz quaternion, translation), one Adam per parameter."""
+    """Camera-to-world pose as a (not necessarily unit) wxyz quaternion and a translation; ``forward()`` is
+    the 4x4 matrix of the normalised quaternion.  ``update_pose(None)`` extrapolates with a constant-velocity
+    model from the pose at the previous call; ``update_pose(T)`` re-seeds the pose and the optimiser state."""
 
     def __init__(self, init_pose: Tensor, *, config: CameraConfig = CameraConfig()):
         super().__init__()
         self.config = config
-        self.quat_cur = nn.Parameter(rotation_matrix_to_quaternion(init_pose[:3, :3].contiguous()))
-        self.t_cur = nn.Parameter(init_pose[:3, 3].clone())
-        self.prev_quat = self.quat_cur.detach().clone()
-        self.prev_t = self.t_cur.detach().clone()
-        self.optimizers = self._create_optimizers()
+        quat, trans = _split_pose(init_pose)
+        self.quat_cur = nn.Parameter(quat)
+        self.t_cur = nn.Parameter(trans)
+        self.prev_quat, self.prev_t = quat.clone(), trans.clone()
+        self.optimizers: List[Optimizer] = self._create_optimizers()
 
-    def update_pose(self, new_pose: Tensor | None = None):
-        with torch.no_grad():
-            if torch.is_tensor(new_pose) and new_pose.shape == (4, 4):
-                self.quat_cur.data = rotation_matrix_to_quaternion(new_pose[:3, :3].contiguous())
-                self.t_cur.data = new_pose[:3, 3]
-                self.optimizers = self._create_optimizers()
-            elif new_pose is None:
-                self.quat_cur.data, self.t_cur.data = self.predict_next_pose()
-            else:
-                raise ValueError("fake new pose")
-
-    def predict_next_pose(self):
-        predicted_quaternion = normalize_quaternion(self.quat_cur + (self.quat_cur - self.prev_quat))
-        predicted_translation = self.t_cur + (self.t_cur - self.prev_t)
-        self.prev_quat, self.prev_t = self.quat_cur.detach().clone(), self.t_cur.detach().clone()
-        return predicted_quaternion, predicted_translation
-
+    # ---- pose
     def forward(self) -> Tensor:
         return construct_full_pose(quat_to_rotation_matrix(self.quat_cur), self.t_cur)
 
-    def optimizer_step(self):
-        for optimizer in self.optimizers:
-            optimizer.step()
+    def predict_next_pose(self) -> Tuple[Tensor, Tensor]:
+        """Constant velocity in parameter space: x_next = x + (x - x_prev); remembers x as the new x_prev."""
+        quat, trans = self.quat_cur.detach(), self.t_cur.detach()
+        nxt = normalize_quaternion(quat + (quat - self.prev_quat)), trans + (trans - self.prev_t)
+        self.prev_quat, self.prev_t = quat.clone(), trans.clone()
+        return nxt
 
-    def optimizer_clean(self):
-        for optimizer in self.optimizers:
-            optimizer.zero_grad(set_to_none=True)
+    def update_pose(self, new_pose: Optional[Tensor] = None) -> None:
+        with torch.no_grad():
+            if new_pose is None:
+                quat, trans = self.predict_next_pose()
+                self.quat_cur.data, self.t_cur.data = quat, trans
+            else:
+                quat, trans = _split_pose(new_pose)
+                self.quat_cur.data, self.t_cur.data = quat, trans
+                self.optimizers = self._create_optimizers()  # fresh moments for the new starting point
 
-    def _create_optimizers(self) -> list[Optimizer]:
-        params = [("quat", self.quat_cur, self.config.quat_lr), ("trans", self.t_cur, self.config.trans_lr)]
-        return [Adam([{"params": param, "lr": lr, "name": name}],
-                     weight_decay=(self.config.quat_opt_reg if name == "quat" else self.config.trans_opt_reg))
-                for name, param, lr in params]
+    # ---- optimiser
+    def _create_optimizers(self) -> List[Optimizer]:
+        cfg = self.config
+        groups = [
+            {"params": [self.quat_cur], "lr": cfg.quat_lr, "weight_decay": cfg.quat_opt_reg, "name": "quat"},
+            {"params": [self.t_cur], "lr": cfg.trans_lr, "weight_decay": cfg.trans_opt_reg, "name": "trans"},
+        ]
+        return [Adam(groups)]
+
+    def optimizer_step(self) -> None:
+        for opt in self.optimizers:
+            opt.step()
+
+    def optimizer_clean(self) -> None:
+        for opt in self.optimizers:
+            opt.zero_grad(set_to_none=True)
 
 
 @dataclass
-class GsConfig:  # model.py:119-133
+class GsConfig:
     init_opa: float = 1.0
     sparse_grad: bool = False
     packed: bool = False
     absgrad: bool = False
     antialiased: bool = False
-    sh_degree: int = 1
+    sh_degree: int = 1  # degree of the spherical harmonics
     near_plane: float = 1e-2
     far_plane: float = 1e10
 
 
 class GSModel(nn.Module):
-    """model.py:136-215: one isotropic Gaussian per point, opacity logit(1.0), identity quaternions,
-    SH degree 1 with only the DC term set."""
+    """One isotropic Gaussian per point: identity rotation, scale from the k-NN distances (or ``scales``),
+    opacity logit(init_opa), SH of degree ``sh_degree`` with only the DC band set from the colours.
+    ``forward`` renders through ``gsplat.rasterization``'s signature (here: the HIP implementation)."""
 
-    def __init__(self, points: Tensor, colors: Tensor, *, config: GsConfig = GsConfig(), scales: Tensor | None = None):
+    def __init__(self, points: Tensor, colors: Tensor, *, config: GsConfig = GsConfig(), scales: Optional[Tensor] = None):
         super().__init__()
         self.config = config
+        n, dev = points.shape[0], points.device
         self.means3d = points
-        self.opacities = torch.logit(torch.full((points.shape[0],), self.config.init_opa, device=self.device))
-        self.scales = init_gs_scales(points) if scales is None else scales
-        self.quats = torch.tensor([1.0, 0.0, 0.0, 0.0], device=self.device).repeat(points.shape[0], 1)
-        sh = torch.zeros((points.shape[0], (self.config.sh_degree + 1) ** 2, 3), device=self.device)
-        sh[:, 0, :] = rgb_to_sh(colors)
         self.colors = colors
-        self.sh0 = sh[:, :1, :]
-        self.shN = sh[:, 1:, :]
+        self.scales = scales if scales is not None else init_gs_scales(points)
+        self.quats = torch.zeros(n, 4, device=dev)
+        self.quats[:, 0] = 1.0
+        self.opacities = torch.logit(torch.full((n,), float(config.init_opa), device=dev))
+        bands = (config.sh_degree + 1) ** 2
+        self.sh0 = rgb_to_sh(colors).reshape(n, 1, 3).to(dev)
+        self.shN = torch.zeros(n, bands - 1, 3, device=dev)
+        self._activated = None  # (key, opacities after sigmoid, [N,K,3] coefficients)
 
-    def __len__(self):
+    def __len__(self) -> int:
         return self.means3d.shape[0]
 
-    def forward(self, camtoworlds: Tensor, Ks: Tensor, width: int, height: int, render_mode: str = "RGB+ED"):
-        assert self.means3d.shape[0] == self.opacities.shape[0]
-        opacities = torch.sigmoid(self.opacities)
-        colors = torch.cat([self.sh0, self.shN], 1)
-        return rasterization(
-            means=self.means3d, quats=self.quats, scales=self.scales, opacities=opacities, colors=colors,
-            sh_degree=self.config.sh_degree, viewmats=torch.linalg.inv(camtoworlds), Ks=Ks, width=width,
-            height=height, packed=self.config.packed, absgrad=self.config.absgrad,
-            sparse_grad=self.config.sparse_grad, far_plane=self.config.far_plane,
-            near_plane=self.config.near_plane, render_mode=render_mode, rasterize_mode="classic")
-
     @property
-    def device(self):
+    def device(self) -> torch.device:
         return self.means3d.device
+
+    def _render_constants(self) -> Tuple[Tensor, Tensor]:
+        src = (self.opacities, self.sh0, self.shN)
+        if any(t.requires_grad for t in src):  # differentiable inputs: a cached graph could not be reused
+            return torch.sigmoid(self.opacities), torch.cat([self.sh0, self.shN], dim=1)
+        key = tuple((id(t), t._version) for t in src)
+        if self._activated is None or self._activated[0] != key:
+            self._activated = (key, torch.sigmoid(self.opacities), torch.cat([self.sh0, self.shN], dim=1))
+        return self._activated[1], self._activated[2]
+
+    def forward(self, camtoworlds: Tensor, Ks: Tensor, width: int, height: int, render_mode: str = "RGB+ED"):
+        cfg = self.config
+        assert self.means3d.shape[0] == self.opacities.shape[0]
+        opacities, coefficients = self._render_constants()
+        return rasterization(means=self.means3d, quats=self.quats, scales=self.scales, opacities=opacities,
+                             colors=coefficients, sh_degree=cfg.sh_degree, viewmats=torch.linalg.inv(camtoworlds),
+                             Ks=Ks, width=width, height=height, packed=cfg.packed, absgrad=cfg.absgrad,
+                             sparse_grad=cfg.sparse_grad, far_plane=cfg.far_plane, near_plane=cfg.near_plane,
+                             render_mode=render_mode, rasterize_mode="classic")
