@@ -172,3 +172,44 @@ def test_geometry_mirror_on_cpu(monkeypatch):
     R = TO.quaternion_to_rotation_matrix(torch.tensor([0.9, 0.1, -0.3, 0.2]) / torch.tensor([0.9, 0.1, -0.3, 0.2]).norm())
     T = Geo.construct_full_pose(R, torch.tensor([0.1, 0.2, 0.3]))
     torch.testing.assert_close(Geo.transform_points(T, pts), pts @ R.T + torch.tensor([0.1, 0.2, 0.3]))
+
+
+def test_pose_tracker_host_loop_matches_the_oracle_tracker(monkeypatch):
+    """PoseTracker(engine="autograd") -- the host side of Runner.train's per-frame body -- with the oracle
+    rasterizer substituted, against the oracle's own tracker loop: same loss trajectory, early-stop
+    bookkeeping and final pose (float32 on both sides)."""
+    from gsplatloc_amd.my_gsplat import geometry as Geo
+    from gsplatloc_amd.my_gsplat import trainer as Tr
+
+    def oracle_rasterization(**kw):
+        return G.rasterization(kw["means"], kw["quats"], kw["scales"], kw["opacities"], kw["colors"], kw["viewmats"],
+                               kw["Ks"], kw["width"], kw["height"], sh_degree=kw["sh_degree"],
+                               near_plane=kw["near_plane"], far_plane=kw["far_plane"], render_mode=kw["render_mode"])
+
+    monkeypatch.setattr(M, "rasterization", oracle_rasterization)
+    monkeypatch.setattr(Geo, "rasterization", oracle_rasterization)
+    H, W = 24, 32
+    K = torch.tensor([[30.0, 0, 15.5], [0, 30.0, 11.5], [0, 0, 1]])
+    vv, uu = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    depth = 2.0 + 0.01 * uu + 0.02 * vv + 0.15 * torch.sin(uu / 3.0) * torch.cos(vv / 4.0)
+    pts = Geo.depth_to_points(depth, K)
+    g = torch.Generator().manual_seed(8)
+    rgb = torch.rand(H * W, 3, generator=g)
+    scales = torch.full((H * W, 3), 0.04)
+    gt_c2w = torch.eye(4)
+    target = Geo.compute_depth_gt(pts, rgb, K[None], gt_c2w[None], H, W).reshape(1, H, W, 1)
+    init = torch.eye(4)
+    init[:3, :3] = TO.quaternion_to_rotation_matrix(torch.tensor([1.0, 0.004, -0.003, 0.002]) / torch.tensor([1.0, 0.004, -0.003, 0.002]).norm())
+    init[:3, 3] = torch.tensor([0.01, -0.008, 0.006])
+    steps = 12
+    cfg = Tr.TrackerConfig(max_steps=steps, min_step=3, patience=4)
+    mine = Tr.PoseTracker(cfg, engine="autograd").track_frame(pts, rgb, target, init.clone(), gt_c2w, K, W, H,
+                                                             scales=scales)
+    ref = TO.track_frame(pts, scales, rgb, target, K, W, H, init.clone(), gt_c2w, max_steps=steps, patience=4,
+                         min_step=3)
+    assert mine.steps == ref.steps and len(mine.losses) == len(ref.losses)
+    torch.testing.assert_close(torch.tensor(mine.losses), torch.tensor(ref.losses), rtol=2e-5, atol=1e-8)
+    assert mine.best_loss == pytest.approx(ref.best_loss, rel=2e-5)
+    assert mine.best_eT == pytest.approx(ref.best_eT, rel=1e-3, abs=1e-7)
+    torch.testing.assert_close(mine.final_c2w, ref.final_c2w, rtol=1e-5, atol=1e-6)
+    assert mine.losses[-1] < mine.losses[0]
