@@ -12,6 +12,8 @@ sources are absent from /root/reference, and the reference's own tests hold no
 golden vector for rendering, loss or gradients.  The
 restatement below follows the published gsplat 1.3.0 algorithm and the
 reference's call sites; it is pinned by float64 finite differences, by an
-independent sequential per-pixel restatement (``oracle/sequential.py``) and by
-invariants -- not by outputs of the reference.
+independent sequential per-pixel restatement (``oracle/sequential.py``), by a
+second implementation in C with hand-derived gradients
+(``oracle/csrc/gsplat_oracle.c``, checked against this package's autograd) and
+by invariants -- not by outputs of the reference.
 """
