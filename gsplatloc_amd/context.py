@@ -77,6 +77,10 @@ class RenderContext:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
         self.capacity = 0
         self.tiny = False
+        # pass 2 of the tiny-splat backward: the measured kernel unless the untested 4-lane variant is asked for
+        import os
+        self._tiny_gather = (self.lib.gsl_tiny_gather4 if os.environ.get("GSLOC_TINY_GATHER") == "4"
+                             else self.lib.gsl_tiny_gather)
         self.trec = self.vcT = None
         self.keys = self.flatten_ids = None
         if capacity is not None:
@@ -147,8 +151,8 @@ class RenderContext:
         if self.tiny:
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), current_stream()),
                   "gsl_tiny_raster_bwd")
-            check(self.lib.gsl_tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W,
-                                           self.H, ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
+            check(self._tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W, self.H,
+                                    ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
                   "gsl_tiny_gather")
         else:
             check(_raster_fn(self.lib, 'bwd')(*common, ptr(self.vacc), current_stream()), "raster_bwd")

@@ -201,6 +201,10 @@ int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int c
                         void* stream);
 int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
                     int height, float* trec, const float* vcT, float* vacc, void* stream);
+/* Experimental variant of gsl_tiny_gather (four lanes per Gaussian, csrc/experimental.hip): same contract; not
+ * yet run on hardware and never selected by default (RenderContext: GSLOC_TINY_GATHER=4). */
+int gsl_tiny_gather4(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
+                     int height, float* trec, const float* vcT, float* vacc, void* stream);
 
 /* Per-pixel-mask compositing (csrc/raster_px.hip): same contract and arguments as
  * gsl_fused_raster_fwd / gsl_fused_raster_bwd, a different kernel organisation: every lane walks the

@@ -1,0 +1,115 @@
+"""Python -> ctypes -> C marshalling of every call the RenderContext and the GraphTracker make, checked on a
+machine WITHOUT a GPU: the HIP runtime refuses the launch and each entry point returns GSL_ERR_HIP (-3), which
+can only happen after ctypes accepted the argument list (count and types) and the entry point's own argument
+validation passed.  A wrong argument list raises ctypes.ArgumentError / TypeError instead, a rejected argument
+returns -1.  Never runs where a GPU is present (the pointers are host pointers)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.skipif(torch.cuda.is_available(), reason="host-pointer calls: only meaningful without a GPU")
+
+
+def _expect_hip_refusal(fn, what):
+    with pytest.raises(RuntimeError, match=r"HIP launch error \(status -3\)"):
+        fn()
+    return what
+
+
+@pytest.mark.parametrize("mode,full,tiny,gather", [("RGB+ED", True, False, None), ("ED", False, True, None),
+                                                   ("RGB+ED", True, True, "4"), ("RGB", True, False, None)])
+def test_render_context_stage_calls_marshal(mode, full, tiny, gather, monkeypatch):
+    import gsplatloc_amd.context as CX
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    monkeypatch.setattr(CX, "current_stream", lambda: None)
+    if gather:
+        monkeypatch.setenv("GSLOC_TINY_GATHER", gather)
+    N, W, H = 500, 64, 48
+    ctx = CX.RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device="cpu", full_grads=full, tile_rows=(1, 3))
+    assert (ctx._tiny_gather is ctx.lib.gsl_tiny_gather4) == (gather == "4")
+    ctx._alloc_isects(4096)
+    if tiny:
+        ctx.tiny = True
+        ctx.trec = torch.zeros(N, 32)
+        ctx.vcT = torch.zeros(H, W, ctx.D)
+    sc = random_scene(N, W, H, sigma_px=1.0)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"],
+           torch.linalg.inv(perturbed_pose()).contiguous(), sc["K"].contiguous())
+    ctx._inputs = inp
+    v, va = torch.zeros(H, W, ctx.D), torch.zeros(H, W, 1)
+    _expect_hip_refusal(lambda: ctx._project(*inp), "project")
+    _expect_hip_refusal(ctx._bin, "bin")
+    _expect_hip_refusal(ctx._raster_fwd, "raster fwd")
+    _expect_hip_refusal(lambda: ctx._raster_bwd(v, va), "raster bwd")
+    if tiny:  # the first call of the pair already refused: exercise the gather on its own as well
+        from gsplatloc_amd._lib import check, ptr
+        _expect_hip_refusal(lambda: check(ctx._tiny_gather(ptr(ctx.Q0), ptr(ctx.Q1), ptr(ctx.radii), ctx.N, ctx.D, ctx.W,
+                                                           ctx.H, ptr(ctx.trec), ptr(ctx.vcT), ptr(ctx.vacc), None),
+                                          "gsl_tiny_gather"), "gather")
+    _expect_hip_refusal(lambda: ctx._project_bwd(full), "project bwd")
+
+
+def test_tracker_kernel_calls_marshal():
+    from gsplatloc_amd._lib import check, load_library, ptr
+
+    lib = load_library()
+    W, H, D = 64, 48, 4
+    render, gt, v_render = torch.zeros(H, W, D), torch.ones(H, W), torch.zeros(H, W, D)
+    ws_bytes = lib.gsl_loss_ws_bytes(W, H)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8)
+    n_part = (H * W + 255) // 256
+    partials = torch.zeros(n_part * 2)
+    pose_f, pose_i = torch.zeros(32), torch.zeros(4, dtype=torch.int32)
+    c2w, viewmat, eye = torch.eye(4), torch.eye(4), torch.eye(4)
+    hist, v_viewmat = torch.zeros(10), torch.zeros(16)
+    _expect_hip_refusal(lambda: check(lib.gsl_tracking_loss(ptr(render), D, ptr(gt), W, H, 0, H, 0.8, 0.2, ptr(v_render),
+                                                            ptr(partials), None, ptr(ws), ws_bytes, None), "loss"), "loss")
+    _expect_hip_refusal(lambda: check(lib.gsl_pose_init(ptr(pose_f), ptr(pose_i), ptr(eye), 5e-4, 1e-3, ptr(c2w),
+                                                        ptr(viewmat), None), "pose_init"), "pose init")
+    _expect_hip_refusal(lambda: check(lib.gsl_pose_step(ptr(pose_f), ptr(pose_i), ptr(v_viewmat), ptr(partials), n_part,
+                                                        None, ptr(eye), W, H, 0.8, 0.2, 0.9, 0.999, 1e-8, 1e-3, 1e-3,
+                                                        0.99, 100, 200, 1, 10, ptr(c2w), ptr(viewmat), ptr(hist), None),
+                                      "pose_step"), "pose step")
+    # k-NN set-up
+    pts, bbox = torch.rand(100, 3), torch.tensor([0.0, 0, 0, 1, 1, 1])
+    kws = lib.gsl_knn_ws_bytes(100)
+    kw = torch.zeros(kws, dtype=torch.uint8)
+    _expect_hip_refusal(lambda: check(lib.gsl_knn_count(ptr(pts), 100, ptr(bbox), ptr(kw), kws, None), "knn"), "knn count")
+
+
+def test_graph_tracker_iteration_marshals_every_call(monkeypatch):
+    """GraphTracker.load_frame() and one _iteration() on host tensors: every C call is reached (the status check
+    is relaxed to 'refused by the HIP runtime') and none is rejected by ctypes or by argument validation."""
+    import gsplatloc_amd.context as CX
+    import gsplatloc_amd.graph_tracker as GT
+    from gsplatloc_amd.my_gsplat import TrackerConfig
+    from gsplatloc_amd.synthetic import frame_pair
+
+    calls = []
+
+    def refused(status, what):
+        calls.append(what)
+        assert status == -3, (what, status)
+
+    class _Stream:
+        def __init__(self, *a, **k):
+            pass
+
+    monkeypatch.setattr(CX, "current_stream", lambda: None)
+    monkeypatch.setattr(GT, "current_stream", lambda: None)
+    monkeypatch.setattr(CX, "check", refused)
+    monkeypatch.setattr(GT, "check", refused)
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    W, H = 64, 48
+    fp = frame_pair(W, H, rot_deg=0.3, trans=0.01)
+    from gsplatloc_amd.my_gsplat.geometry import depth_to_points
+    pts = depth_to_points(fp["depth0"], fp["K"])
+    gt = GT.GraphTracker(pts.shape[0], W, H, TrackerConfig(max_steps=5), device="cpu", use_graph=False)
+    gt.load_frame(pts, fp["rgb"], torch.full((pts.shape[0], 3), 0.01), fp["depth1"], fp["c2w0"], fp["c2w1"], fp["K"])
+    n_setup = len(calls)
+    gt._iteration()
+    assert calls[:n_setup] == ["gsl_pose_init", "gsl_fused_project"]
+    # nothing was projected (the launch was refused), so every r_cull is 0 and calibration picked the tiny backward
+    assert gt.rc.tiny
+    assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_bin", "raster_fwd", "gsl_tracking_loss",
+                               "gsl_tiny_raster_bwd", "gsl_tiny_gather", "gsl_fused_project_bwd", "gsl_pose_step"]
