@@ -237,6 +237,16 @@ def pose_opt_rate(dev):
             "loss_last": res.losses[-1], "eT_init_m": 0.01, "best_eT_m": res.best_eT}
 
 
+def guarded(fn, *a, **k):
+    """Side measurements must not cost the headline line: report their failure instead of raising."""
+    try:
+        return fn(*a, **k)
+    except Exception as exc:  # noqa: BLE001 - anything: the JSON line still has to be printed
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -351,7 +361,9 @@ def main():
     stage_ms = {}
     if rank == 0:
         from gsplatloc_amd import context as C
-        stage_ms = C.time_stages(ctx, args_in, v_render, v_alphas, full, steps=min(args.steps, 20))
+        stage_ms = guarded(C.time_stages, ctx, args_in, v_render, v_alphas, full, steps=min(args.steps, 20))
+        if "error" in stage_ms:
+            stage_ms = {}
 
     if rank == 0:
         I_all = n_total if world == 1 else None
@@ -359,8 +371,8 @@ def main():
         bytes_stage = algorithmic_bytes(n_local, n_total, P if world == 1 else (rows[1] - rows[0]) * 16 * W, 4,
                                         ctx.n_tiles, full)
         dom = max(stage_ms, key=stage_ms.get) if stage_ms else "raster_bwd"
-        dom_ms = stage_ms.get(dom, float("nan"))
-        achieved = bytes_stage[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms else None
+        dom_ms = stage_ms.get(dom)  # None if the stage timing pass failed
+        achieved = bytes_stage[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms else None
         out = {
             "metric": "Gaussians/s fwd+bwd @1M splats 1200x680",
             "value": N / (dt / args.steps),
@@ -395,15 +407,15 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = guarded(cpu_baseline, args)
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_tracker:
-            out["pose_opt"] = pose_opt_rate(dev)
+            out["pose_opt"] = guarded(pose_opt_rate, dev)
         if world == 1 and not args.no_variants:
             # same N and image, the other synthetic inputs of SURVEY.md 8(d): sigma_px -> 0 is the regime of the
             # reference's as-coded kNN scales; "raster" is the Gaussian order of a back-projected depth frame
-            out["variants"] = [variant_rate(dev, N, W, H, s_, o_) for s_, o_ in
+            out["variants"] = [guarded(variant_rate, dev, N, W, H, s_, o_) for s_, o_ in
                                ((1.0, "raster"), (0.0, "random"), (0.0, "raster"))]
         print(json.dumps(out))
     if dist is not None:
