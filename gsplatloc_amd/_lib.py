@@ -14,7 +14,9 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgsloc_hip.so")
+# GSLOC_AOS=1 selects the build variant with interleaved 64-byte records (csrc: -DGSL_QS=4); default: the measured one
+_VARIANT = "_aos" if os.environ.get("GSLOC_AOS") == "1" else ""
+_LIB_PATH = os.path.join(_HERE, f"libgsloc_hip{_VARIANT}.so")
 _lib: Optional[ctypes.CDLL] = None
 
 P = c_void_p  # every device pointer travels as void*
@@ -22,6 +24,7 @@ P = c_void_p  # every device pointer travels as void*
 _SIGNATURES = {
     "gsl_version": (c_char_p, []),
     "gsl_status_string": (c_char_p, [c_int]),
+    "gsl_record_stride": (c_int, []),
     "gsl_project_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
                                 P, P, P, P, P, P]),
     "gsl_project_bwd_ws_bytes": (c_size_t, [c_int]),
@@ -87,7 +90,7 @@ def exported_symbols():
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libgsloc_hip.so (in-tree)."""
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1))]
+    cmd = ["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "all", "aos"]
     if force:
         subprocess.run(["make", "-C", csrc, "clean"], check=True, capture_output=not verbose)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from ._lib import check, current_stream, load_library, ptr
-from .fused import _MODES, MAX_STRIP_TILES, _raster_fn, tile_n_bits
+from .fused import _MODES, MAX_STRIP_TILES, _raster_fn, alloc_records, tile_n_bits
 
 
 TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
@@ -50,9 +50,7 @@ class RenderContext:
         f32, i32 = torch.float32, torch.int32
         N = self.N
         self.radii = torch.zeros(N, dtype=i32, device=dev)
-        self.Q0 = torch.zeros(N, 4, dtype=f32, device=dev)
-        self.Q1 = torch.zeros(N, 4, dtype=f32, device=dev)
-        self.Q2 = torch.zeros(N, 4, dtype=f32, device=dev) if self.rgb else None
+        self.Q0, self.Q1, self.Q2 = alloc_records(self.lib, N, self.rgb, dev, zero=True)
         self.comps = torch.zeros(N, dtype=f32, device=dev) if self.antialiased else None
         self.offs = torch.zeros(self.n_tiles + 1, dtype=i32, device=dev)
         self.n_is = torch.zeros(1, dtype=i32, device=dev)

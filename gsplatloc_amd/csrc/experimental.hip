@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_tiny_gather4(const float4* __restrict__
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       row[0] = z;
       row[1] = z;
-      float4 q0 = Q0[gid], qc = Q1[gid];
+      float4 q0 = GSL_Q(Q0, gid), qc = GSL_Q(Q1, gid);
       int pcol0 = xp_tiny_origin(q0.x, qc.w), prow = xp_tiny_origin(q0.y, qc.w) + r;
       float dy = q0.y - ((float)prow + 0.5f);
       bool row_in = (unsigned)prow < (unsigned)H;

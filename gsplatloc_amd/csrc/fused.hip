@@ -103,8 +103,8 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
       }
     }
     radii[i] = radius;
-    Q0[i] = o0;
-    Q1[i] = o1;
+    GSL_Q(Q0, i) = o0;
+    GSL_Q(Q1, i) = o1;
     if (comps) comps[i] = comp;
     if (RGB) {
       float c0 = 0.f, c1 = 0.f, c2 = 0.f;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
         }
         c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
       }
-      Q2[i] = make_float4(c0, c1, c2, 0.f);
+      GSL_Q(Q2, i) = make_float4(c0, c1, c2, 0.f);
     }
     if (radius > 0) {
       tile_rect(o0.x, o0.y, radius, 16, tile_w, tile_h, xmin, ymin, xmax, ymax);
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
   if (i < N) {
     int r = radii[i];
     if (r > 0) {
-      float4 q0 = Q0[i];
+      float4 q0 = GSL_Q(Q0, i);
       tile_rect(q0.x, q0.y, r, 16, tile_w, tile_h, xmin, ymin, xmax, ymax);
       ymin = max(ymin, ty0);
       ymax = min(ymax, ty1);
@@ -307,9 +307,9 @@ __global__ __launch_bounds__(256) void k_fraster_fwd(
     int bsize = (int)min((long long)256, re - bstart);
     if (tid < bsize) {
       int g = flatten_ids[bstart + tid];
-      sb.s0[tid] = Q0[g];
-      sb.s1[tid] = Q1[g];
-      if (RGB) sb.s2[tid] = Q2[g];
+      sb.s0[tid] = GSL_Q(Q0, g);
+      sb.s1[tid] = GSL_Q(Q1, g);
+      if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
     }
     __syncthreads();
     for (int c = 0; c < bsize && donem != ~0ull; c += 64) {
@@ -452,9 +452,9 @@ __device__ __forceinline__ void fraster_bwd_body(
     if (tid < bsize) {
       int g = flatten_ids[bend - tid];
       sb.id[tid] = g;
-      sb.s0[tid] = Q0[g];
-      sb.s1[tid] = Q1[g];
-      if (RGB && CG == D) sb.s2[tid] = Q2[g];
+      sb.s0[tid] = GSL_Q(Q0, g);
+      sb.s1[tid] = GSL_Q(Q1, g);
+      if (RGB && CG == D) sb.s2[tid] = GSL_Q(Q2, g);
     }
 #pragma unroll
     for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
     p.covar = quat_scale_to_covar(q, s);
     p.covar_c = mul_bt(mul(cam.R, p.covar), cam.R);
     persp_mid(cam, W, H, p);
-    float4 q1 = Q1[i];
+    float4 q1 = GSL_Q(Q1, i);
     project_vjp<FULL>(cam, eps2d, p, q, s, q1.x, q1.y, q1.z, vm2x, vm2y, vdepth, v_ca, v_cb, v_cc, antialiased != 0,
                       comp, vcomp, acc15, vmean, vq, vs);
     sh_live = RGB && (sh_degree >= 0) && (vrgb[0] != 0.f || vrgb[1] != 0.f || vrgb[2] != 0.f);

@@ -92,6 +92,15 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
   return c;
 }
 
+// Per-Gaussian records Q0/Q1/Q2 (float4 each) are indexed as Qk[g * GSL_QS].  GSL_QS = 1: three separate arrays
+// (the measured layout).  GSL_QS = 4 (build variant libgsloc_hip_aos.so): the three pointers address one
+// interleaved array of 64-byte rows [Q0 | Q1 | Q2 | pad], so a gather of one splat touches one 128-byte line
+// instead of three.
+#ifndef GSL_QS
+#define GSL_QS 1
+#endif
+#define GSL_Q(arr, g) (arr)[(g) * GSL_QS]
+
 // DPP lane exchange (no LDS traffic).  Lanes a row_mask disables contribute 0.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_get(float v) {

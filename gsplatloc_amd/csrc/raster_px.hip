@@ -132,11 +132,11 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
     if (tid < bsize) {
       int g = flatten_ids[bstart + tid];
-      r0 = Q0[g];
-      r1 = Q1[g];
+      r0 = GSL_Q(Q0, g);
+      r1 = GSL_Q(Q1, g);
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
-      if (RGB) sb.s2[tid] = Q2[g];
+      if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     for (int c = 0; c < n; c += 64) {
@@ -277,11 +277,11 @@ __device__ __forceinline__ void praster_bwd_body(
     if (tid < bsize) {
       int g = flatten_ids[bend - tid];
       sb.id[tid] = g;
-      r0 = Q0[g];
-      r1 = Q1[g];
+      r0 = GSL_Q(Q0, g);
+      r1 = GSL_Q(Q1, g);
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
-      if (RGBS) sb.s2[tid] = Q2[g];
+      if (RGBS) sb.s2[tid] = GSL_Q(Q2, g);
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     // slots below t_first hold splats behind everything this quadrant composited
@@ -569,11 +569,11 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
     if (tid < bsize) {
       int g = flatten_ids[bend - tid];
       sb.id[tid] = g;
-      r0 = Q0[g];
-      r1 = Q1[g];
+      r0 = GSL_Q(Q0, g);
+      r1 = GSL_Q(Q1, g);
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
-      if (RGB) sb.s2[tid] = Q2[g];
+      if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     int t_first = (int)max((long long)0, bend - (long long)wave_final);
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void k_tiny_gather(const float4* __restrict__ 
     float2 wf = trec[(size_t)gid * 16 + s];
     if (wf.x != 0.f || wf.y != 0.f) {
       trec[(size_t)gid * 16 + s] = make_float2(0.f, 0.f);
-      float4 q0 = Q0[gid], qc = Q1[gid];
+      float4 q0 = GSL_Q(Q0, gid), qc = GSL_Q(Q1, gid);
       int pcol = tiny_origin(q0.x, qc.w) + (s & 3), prow = tiny_origin(q0.y, qc.w) + (s >> 2);
       float dx = q0.x - ((float)pcol + 0.5f), dy = q0.y - ((float)prow + 0.5f);
       float gx = qc.x * dx + qc.y * dy, gy = qc.y * dx + qc.z * dy;

@@ -39,6 +39,19 @@ def tile_n_bits(n_tiles: int) -> int:
     return int(math.floor(math.log2(n_tiles))) + 1
 
 
+def alloc_records(lib, N: int, rgb: bool, dev, zero: bool = False):
+    """The per-Gaussian record arrays Q0, Q1, Q2 ([N,4] each; Q2 None without colours) in the layout the loaded
+    library expects (gsl_record_stride): three separate arrays, or columns of one [N,16] array of 64-byte rows."""
+    make = torch.zeros if zero else torch.empty
+    if lib.gsl_record_stride() == 1:
+        Q0 = make(N, 4, dtype=torch.float32, device=dev)
+        Q1 = make(N, 4, dtype=torch.float32, device=dev)
+        Q2 = make(N, 4, dtype=torch.float32, device=dev) if rgb else None
+        return Q0, Q1, Q2
+    rows = make(N, 16, dtype=torch.float32, device=dev)
+    return rows[:, 0:4], rows[:, 4:8], (rows[:, 8:12] if rgb else None)
+
+
 class _FusedRasterization(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, viewmat, K, cfg, meta):
@@ -52,9 +65,7 @@ class _FusedRasterization(torch.autograd.Function):
         n_tiles = tw * th
         f32, i32 = torch.float32, torch.int32
         radii = torch.empty(N, dtype=i32, device=dev)
-        Q0 = torch.empty(N, 4, dtype=f32, device=dev)
-        Q1 = torch.empty(N, 4, dtype=f32, device=dev)
-        Q2 = torch.empty(N, 4, dtype=f32, device=dev) if rgb else None
+        Q0, Q1, Q2 = alloc_records(lib, N, rgb, dev)
         comps = torch.empty(N, dtype=f32, device=dev) if antialiased else None
         tpg = torch.empty(N, dtype=i32, device=dev)
         offs = torch.empty(n_tiles + 1, dtype=i32, device=dev)

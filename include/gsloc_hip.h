@@ -42,6 +42,11 @@ typedef enum gsl_status {
 const char* gsl_version(void);
 /* Text for a gsl_status. */
 const char* gsl_status_string(int status);
+/* Layout of the per-Gaussian records of the fused path.  1 (libgsloc_hip.so): Q0, Q1, Q2 are three arrays of
+ * N float4.  4 (build variant libgsloc_hip_aos.so, -DGSL_QS=4, not yet measured): the three pointers address
+ * columns 0, 1, 2 of ONE array of N rows of 4 float4 (64 bytes), i.e. Qk = base + 4*k floats and record g of Qk
+ * lives at Qk + 16*g floats. */
+int gsl_record_stride(void);
 
 /* ---- projection: gsplat.fully_fused_projection fwd/bwd (IDX:14351, IDX:14270) ----
  * One camera.  viewmat[16] world->camera row-major, K[9] intrinsics, both on device.

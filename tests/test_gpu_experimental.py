@@ -1,0 +1,66 @@
+"""Parity of the code paths that have not run on hardware yet (written after round 1's GPU access ended):
+the 4-lanes-per-Gaussian tiny-splat gather (GSLOC_TINY_GATHER=4) and the library variant with interleaved
+64-byte records (GSLOC_AOS=1).  Each runs in a child process (the switches are read at import) and is compared
+with the default path of this process.  Skipped unless GSLOC_EXPERIMENTAL=1."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("GSLOC_EXPERIMENTAL") != "1",
+                                 reason="set GSLOC_EXPERIMENTAL=1 (paths not yet run on hardware)")]
+
+CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from gsplatloc_amd.context import RenderContext
+from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+N, W, H, sigma = 60_011, 640, 470, float(sys.argv[3])
+dev = torch.device("cuda")
+sc = random_scene(N, W, H, sigma_px=sigma, device=dev)
+V = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], V, sc["K"].contiguous())
+ctx.calibrate(*inp)
+g = torch.Generator().manual_seed(3)
+v = torch.randn(H, W, 4, generator=g).to(dev)
+va = torch.randn(H, W, 1, generator=g).to(dev)
+for _ in range(2):
+    render, alphas = ctx.forward(*inp)
+    grads = ctx.backward(v, va, full=True)
+torch.cuda.synchronize()
+ctx.check_capacity()
+out = {"render": render.cpu(), "alphas": alphas.cpu(), "tiny": ctx.tiny, "stride": ctx.lib.gsl_record_stride()}
+out.update({k: t.cpu() for k, t in grads.items()})
+torch.save(out, sys.argv[2])
+"""
+
+
+def _run(tmp_path, tag, sigma, env):
+    out = tmp_path / f"{tag}.pt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    res = subprocess.run([sys.executable, "-c", CHILD, root, str(out), str(sigma)], env=e, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return torch.load(out, weights_only=True)
+
+
+@pytest.mark.parametrize("sigma,env,expect", [
+    (0.0, {"GSLOC_TINY_GATHER": "4"}, {"tiny": True, "stride": 1}),
+    (0.0, {"GSLOC_AOS": "1"}, {"tiny": True, "stride": 4}),
+    (1.0, {"GSLOC_AOS": "1"}, {"tiny": False, "stride": 4}),
+    (0.0, {"GSLOC_AOS": "1", "GSLOC_TINY_GATHER": "4"}, {"tiny": True, "stride": 4}),
+])
+def test_experimental_path_matches_default(tmp_path, sigma, env, expect):
+    base = _run(tmp_path, "base", sigma, {"GSLOC_AOS": "0", "GSLOC_TINY_GATHER": "16"})
+    got = _run(tmp_path, "exp", sigma, env)
+    assert base["stride"] == 1 and got["stride"] == expect["stride"] and got["tiny"] == expect["tiny"] == base["tiny"]
+    assert torch.equal(got["render"], base["render"]) and torch.equal(got["alphas"], base["alphas"])
+    for k in ("viewmat", "means", "quats", "scales", "opacities", "colors"):
+        a, b = got[k].double(), base[k].double()
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
