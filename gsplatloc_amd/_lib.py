@@ -14,8 +14,10 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GSLOC_AOS=1 selects the build variant with interleaved 64-byte records (csrc: -DGSL_QS=4); default: the measured one
-_VARIANT = "_aos" if os.environ.get("GSLOC_AOS") == "1" else ""
+# Build variants (csrc/Makefile: aos = interleaved 64-byte records, occ5 = backward at 5 waves/SIMD) are loaded only
+# on request -- GSLOC_LIB_VARIANT=<name>, or GSLOC_AOS=1 for "aos"; default: the measured library
+_VARIANT = os.environ.get("GSLOC_LIB_VARIANT", "aos" if os.environ.get("GSLOC_AOS") == "1" else "")
+_VARIANT = f"_{_VARIANT}" if _VARIANT else ""
 _LIB_PATH = os.path.join(_HERE, f"libgsloc_hip{_VARIANT}.so")
 _lib: Optional[ctypes.CDLL] = None
 
@@ -90,7 +92,7 @@ def exported_symbols():
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libgsloc_hip.so (in-tree)."""
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "all", "aos"]
+    cmd = ["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "all", "variants"]
     if force:
         subprocess.run(["make", "-C", csrc, "clean"], check=True, capture_output=not verbose)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -572,8 +572,16 @@ __device__ __forceinline__ void fraster_bwd_body(
   }
 }
 
+// Build variant -DGSL_BWD_WAVES=n asks the register allocator for n waves per SIMD (the default build lands at
+// 120 VGPRs = 4 waves; 5 waves = 96 VGPRs costs 13 spilled registers).  Unset in the measured library.
+#ifdef GSL_BWD_WAVES
+#define GSL_BWD_ATTR __attribute__((amdgpu_waves_per_eu(GSL_BWD_WAVES, GSL_BWD_WAVES)))
+#else
+#define GSL_BWD_ATTR
+#endif
+
 template <int D, bool ED>
-__global__ __launch_bounds__(256) void k_fraster_bwd(
+__global__ __launch_bounds__(256) GSL_BWD_ATTR void k_fraster_bwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,

@@ -1,6 +1,7 @@
 """Parity of the code paths that have not run on hardware yet (written after round 1's GPU access ended):
-the 4-lanes-per-Gaussian tiny-splat gather (GSLOC_TINY_GATHER=4) and the library variant with interleaved
-64-byte records (GSLOC_AOS=1).  Each runs in a child process (the switches are read at import) and is compared
+the 4-lanes-per-Gaussian tiny-splat gather (GSLOC_TINY_GATHER=4), the library variant with interleaved
+64-byte records (GSLOC_AOS=1) and the one whose compositing backward is compiled for 5 waves per SIMD
+(GSLOC_LIB_VARIANT=occ5).  Each runs in a child process (the switches are read at import) and is compared
 with the default path of this process.  Skipped unless GSLOC_EXPERIMENTAL=1."""
 import os
 import subprocess
@@ -55,9 +56,10 @@ def _run(tmp_path, tag, sigma, env):
     (0.0, {"GSLOC_AOS": "1"}, {"tiny": True, "stride": 4}),
     (1.0, {"GSLOC_AOS": "1"}, {"tiny": False, "stride": 4}),
     (0.0, {"GSLOC_AOS": "1", "GSLOC_TINY_GATHER": "4"}, {"tiny": True, "stride": 4}),
+    (1.0, {"GSLOC_LIB_VARIANT": "occ5"}, {"tiny": False, "stride": 1}),
 ])
 def test_experimental_path_matches_default(tmp_path, sigma, env, expect):
-    base = _run(tmp_path, "base", sigma, {"GSLOC_AOS": "0", "GSLOC_TINY_GATHER": "16"})
+    base = _run(tmp_path, "base", sigma, {"GSLOC_AOS": "0", "GSLOC_TINY_GATHER": "16", "GSLOC_LIB_VARIANT": ""})
     got = _run(tmp_path, "exp", sigma, env)
     assert base["stride"] == 1 and got["stride"] == expect["stride"] and got["tiny"] == expect["tiny"] == base["tiny"]
     assert torch.equal(got["render"], base["render"]) and torch.equal(got["alphas"], base["alphas"])
