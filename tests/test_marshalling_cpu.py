@@ -113,3 +113,37 @@ def test_graph_tracker_iteration_marshals_every_call(monkeypatch):
     assert gt.rc.tiny
     assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_bin", "raster_fwd", "gsl_tracking_loss",
                                "gsl_tiny_raster_bwd", "gsl_tiny_gather", "gsl_fused_project_bwd", "gsl_pose_step"]
+
+
+@pytest.mark.parametrize("mode,sh_degree", [("RGB+ED", 1), ("ED", None), ("RGB", None)])
+def test_fused_autograd_function_marshals(mode, sh_degree, monkeypatch):
+    """The gsplat-compatible entry's autograd function (fused.py), forward and backward, on host tensors."""
+    import gsplatloc_amd.fused as F
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    calls = []
+
+    def refused(status, what):  # 0: nothing to launch (no intersections); -3: launch refused; never a rejected argument
+        calls.append(what)
+        assert status in (0, -3), (what, status)
+
+    monkeypatch.setattr(F, "check", refused)
+    monkeypatch.setattr(F, "current_stream", lambda: None)
+    monkeypatch.setattr(torch, "empty", torch.zeros)  # the intersection count is read back from an output buffer
+    N, W, H = 300, 64, 48
+    sc = random_scene(N, W, H, sigma_px=1.0)
+    colors = sc["sh"] if sh_degree is not None else torch.rand(N, 3)
+    ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities")]
+    col = colors.clone().requires_grad_()
+    V = torch.linalg.inv(perturbed_pose()).contiguous().requires_grad_()
+    cfg = (W, H, -1 if sh_degree is None else sh_degree, mode, 0.3, 0.01, 1e10, 0.0, False, 0, 3, True)
+    raw = {}
+    render, alphas, last = F._FusedRasterization.apply(*ins, col, V, sc["K"].contiguous(), cfg, raw)
+    assert render.shape == (H, W, F._MODES[mode][0]) and alphas.shape == (H, W, 1) and last.shape == (H, W)
+    assert {"radii", "Q0", "Q1", "tile_offsets", "flatten_ids", "n_isects"} <= set(raw)
+    assert raw["Q0"].shape == (N, 4) and raw["Q0"].is_contiguous()
+    (render.sum() + alphas.sum()).backward()
+    assert calls[:3] == ["gsl_fused_project", "gsl_fused_bin", "gsl_fused_raster_fwd"]
+    assert calls[3:] == ["gsl_fused_raster_bwd", "gsl_fused_project_bwd"]
+    assert V.grad is not None and V.grad.shape == (4, 4) and ins[0].grad.shape == (N, 3)
+    assert (col.grad is not None) == mode.startswith("RGB")
