@@ -66,3 +66,31 @@ def test_experimental_path_matches_default(tmp_path, sigma, env, expect):
     for k in ("viewmat", "means", "quats", "scales", "opacities", "colors"):
         a, b = got[k].double(), base[k].double()
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12, k
+
+
+def test_legacy_pair_on_the_gpu():
+    """project_gaussians / rasterize_gaussians over the HIP stage operators against the fused HIP rasterization
+    (the glue itself is covered on the CPU by tests/test_legacy_cpu.py; this is its first run on hardware)."""
+    import gsplat
+    from tests.scenes import random_scene, small_pose
+
+    N, W, H = 4000, 200, 150
+    sc = random_scene(N, W, H, seed=5, sigma_px=2.0, aniso=True, opacity=(0.3, 1.0), dtype=torch.float32)
+    V = torch.linalg.inv(small_pose(1.0, 0.03, dtype=torch.float32)).cuda()
+    cu = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    fx, fy, cx, cy = (float(sc["K"][0, 0]), float(sc["K"][1, 1]), float(sc["K"][0, 2]), float(sc["K"][1, 2]))
+    m1, V1 = cu["means"].clone().requires_grad_(), V.clone().requires_grad_()
+    xys, depths, radii, conics, comp, hit, cov3d = gsplat.project_gaussians(
+        m1, cu["scales"], 1.0, cu["quats"], V1, fx, fy, cx, cy, H, W, 16)
+    img, alpha = gsplat.rasterize_gaussians(xys, depths, radii, conics, hit, cu["rgbs"], cu["opacities"][:, None], H, W, 16,
+                                            return_alpha=True)
+    m2, V2 = cu["means"].clone().requires_grad_(), V.clone().requires_grad_()
+    rc, ra, meta = gsplat.rasterization(m2, cu["quats"], cu["scales"], cu["opacities"], cu["rgbs"], V2[None], cu["K"][None],
+                                        W, H, render_mode="RGB")
+    assert torch.equal(radii, meta["radii"][0]) and cov3d.shape == (N, 6)
+    assert float((img - rc[0]).abs().max()) < 1e-5 and float((alpha - ra[0, ..., 0]).abs().max()) < 1e-5
+    w = torch.linspace(0.5, 1.5, img.numel(), device="cuda").reshape(img.shape)
+    (img * w).sum().backward()
+    (rc[0] * w).sum().backward()
+    assert float((V1.grad - V2.grad).abs().max()) < 1e-4 * float(V2.grad.abs().max())
+    assert float((m1.grad - m2.grad).abs().max()) < 1e-4 * float(m2.grad.abs().max())
