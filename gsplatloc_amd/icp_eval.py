@@ -55,7 +55,10 @@ def run_icp_sequence(frames, registration_type: str = "GICP", max_images: int = 
     iters: List[int] = []
     prev_pose: Optional[np.ndarray] = None
     t0 = time.perf_counter()
-    for i, frame in enumerate(frames):
+    # the readers signal "out of range" with ValueError (as the reference's do), which the sequence iteration
+    # protocol does not treat as the end: walk sized collections by index
+    walk = (frames[i] for i in range(min(len(frames), max_images))) if hasattr(frames, "__len__") else frames
+    for i, frame in enumerate(walk):
         pts = np.asarray(frame.points.cpu() if hasattr(frame.points, "cpu") else frame.points, dtype=np.float64)
         pose_gt = np.asarray(frame.pose.cpu() if hasattr(frame.pose, "cpu") else frame.pose, dtype=np.float64)
         pts = pts.reshape(-1, pts.shape[-1])[::stride, :3]
