@@ -147,3 +147,38 @@ def test_fused_autograd_function_marshals(mode, sh_degree, monkeypatch):
     assert calls[3:] == ["gsl_fused_raster_bwd", "gsl_fused_project_bwd"]
     assert V.grad is not None and V.grad.shape == (4, 4) and ins[0].grad.shape == (N, 3)
     assert (col.grad is not None) == mode.startswith("RGB")
+
+
+def test_sequence_evaluation_cli_on_host_tensors(tmp_path, monkeypatch, capsys):
+    """python -m gsplatloc_amd.eval end to end on Replica-format files with every kernel launch refused: the
+    reader, the Parser, the GraphTracker glue, the report writer and the argument parser all run."""
+    import functools
+    import json
+
+    import gsplatloc_amd.context as CX
+    import gsplatloc_amd.eval as EV
+    import gsplatloc_amd.graph_tracker as GT
+    from gsplatloc_amd.data import Parser
+    from tests.test_data import write_replica
+
+    def refused(status, what):
+        assert status in (0, -3), (what, status)
+
+    class _Stream:
+        def __init__(self, *a, **k):
+            pass
+
+    monkeypatch.setattr(CX, "current_stream", lambda: None)
+    monkeypatch.setattr(GT, "current_stream", lambda: None)
+    monkeypatch.setattr(CX, "check", refused)
+    monkeypatch.setattr(GT, "check", refused)
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(EV, "Parser", functools.partial(Parser, device="cpu"))
+    monkeypatch.setattr(EV, "GraphTracker", functools.partial(GT.GraphTracker, use_graph=False))  # no graph capture here
+    write_replica(tmp_path, n=3)
+    out = tmp_path / "res.json"
+    EV.main(["--dataset", "Replica", "--rooms", "room0", "--root", str(tmp_path), "--num-iters", "3", "--no-normalize",
+             "--max-frames", "2", "--out", str(out)])
+    rep = json.loads(out.read_text())["room0"]["gsplatloc_amd"]
+    assert rep["frames"] == 2 and set(rep) >= {"ATE", "AAE", "frames_with_result", "mean_steps", "seconds"}
+    assert "room0" in capsys.readouterr().out
