@@ -66,6 +66,8 @@ _SIGNATURES = {
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_tiny_gather": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
     "gsl_tiny_gather4": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "gsl_tiny_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
+                                     P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                     P, P, P, P, P, P, P, P]),
     "gsl_debug_reduce_scatter": (c_int, [P, P, P]),

@@ -79,6 +79,8 @@ class RenderContext:
         import os
         self._tiny_gather = (self.lib.gsl_tiny_gather4 if os.environ.get("GSLOC_TINY_GATHER") == "4"
                              else self.lib.gsl_tiny_gather)
+        # untested variant: the gather runs inside the projection backward (one kernel, rows stay in LDS)
+        self._tiny_fused = os.environ.get("GSLOC_TINY_FUSED") == "1"
         self.trec = self.vcT = None
         self.keys = self.flatten_ids = None
         if capacity is not None:
@@ -149,14 +151,25 @@ class RenderContext:
         if self.tiny:
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), current_stream()),
                   "gsl_tiny_raster_bwd")
-            check(self._tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W, self.H,
-                                    ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
-                  "gsl_tiny_gather")
+            if not self._tiny_fused:
+                check(self._tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W, self.H,
+                                        ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
+                      "gsl_tiny_gather")
         else:
             check(_raster_fn(self.lib, 'bwd')(*common, ptr(self.vacc), current_stream()), "raster_bwd")
 
     def _project_bwd(self, full: bool) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
+        if self.tiny and self._tiny_fused:
+            check(self.lib.gsl_tiny_project_bwd(
+                ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
+                self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
+                ptr(self.radii), ptr(self.Q0), ptr(self.Q1), ptr(self.comps), ptr(self.trec), ptr(self.vcT),
+                ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
+                ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
+                ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
+                self.n_tiles, current_stream()), "gsl_tiny_project_bwd")
+            return
         check(self.lib.gsl_fused_project_bwd(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,

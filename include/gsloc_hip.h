@@ -210,6 +210,15 @@ int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int 
  * yet run on hardware and never selected by default (RenderContext: GSLOC_TINY_GATHER=4). */
 int gsl_tiny_gather4(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
                      int height, float* trec, const float* vcT, float* vacc, void* stream);
+/* Experimental: gsl_tiny_gather and gsl_fused_project_bwd as ONE kernel (csrc/experimental.hip) -- the gradient
+ * rows stay in shared memory.  Arguments of gsl_fused_project_bwd with `vacc` replaced by what the gather reads
+ * (Q0, trec, vcT); trec is cleared as by gsl_tiny_gather.  Not yet run on hardware; RenderContext: GSLOC_TINY_FUSED=1. */
+int gsl_tiny_project_bwd(const float* means, const float* quats, const float* scales, const float* opacities,
+                         const float* colors, int sh_degree, int K_sh, const float* viewmat, const float* K, int N,
+                         int width, int height, float eps2d, int antialiased, int channels, const int32_t* radii,
+                         const float* Q0, const float* Q1, const float* compensations, float* trec, const float* vcT,
+                         float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
+                         float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
 /* Per-pixel-mask compositing (csrc/raster_px.hip): same contract and arguments as
  * gsl_fused_raster_fwd / gsl_fused_raster_bwd, a different kernel organisation: every lane walks the

@@ -57,9 +57,10 @@ def _run(tmp_path, tag, sigma, env):
     (1.0, {"GSLOC_AOS": "1"}, {"tiny": False, "stride": 4}),
     (0.0, {"GSLOC_AOS": "1", "GSLOC_TINY_GATHER": "4"}, {"tiny": True, "stride": 4}),
     (1.0, {"GSLOC_LIB_VARIANT": "occ5"}, {"tiny": False, "stride": 1}),
+    (0.0, {"GSLOC_TINY_FUSED": "1"}, {"tiny": True, "stride": 1}),
 ])
 def test_experimental_path_matches_default(tmp_path, sigma, env, expect):
-    base = _run(tmp_path, "base", sigma, {"GSLOC_AOS": "0", "GSLOC_TINY_GATHER": "16", "GSLOC_LIB_VARIANT": ""})
+    base = _run(tmp_path, "base", sigma, {"GSLOC_AOS": "0", "GSLOC_TINY_GATHER": "16", "GSLOC_LIB_VARIANT": "", "GSLOC_TINY_FUSED": "0"})
     got = _run(tmp_path, "exp", sigma, env)
     assert base["stride"] == 1 and got["stride"] == expect["stride"] and got["tiny"] == expect["tiny"] == base["tiny"]
     assert torch.equal(got["render"], base["render"]) and torch.equal(got["alphas"], base["alphas"])

@@ -16,13 +16,16 @@ def _expect_hip_refusal(fn, what):
 
 
 @pytest.mark.parametrize("mode,full,tiny,gather", [("RGB+ED", True, False, None), ("ED", False, True, None),
-                                                   ("RGB+ED", True, True, "4"), ("RGB", True, False, None)])
+                                                   ("RGB+ED", True, True, "4"), ("RGB", True, False, None),
+                                                   ("RGB+ED", True, True, "fused"), ("ED", False, True, "fused")])
 def test_render_context_stage_calls_marshal(mode, full, tiny, gather, monkeypatch):
     import gsplatloc_amd.context as CX
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
 
     monkeypatch.setattr(CX, "current_stream", lambda: None)
-    if gather:
+    if gather == "fused":
+        monkeypatch.setenv("GSLOC_TINY_FUSED", "1")
+    elif gather:
         monkeypatch.setenv("GSLOC_TINY_GATHER", gather)
     N, W, H = 500, 64, 48
     ctx = CX.RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device="cpu", full_grads=full, tile_rows=(1, 3))
@@ -46,7 +49,12 @@ def test_render_context_stage_calls_marshal(mode, full, tiny, gather, monkeypatc
         _expect_hip_refusal(lambda: check(ctx._tiny_gather(ptr(ctx.Q0), ptr(ctx.Q1), ptr(ctx.radii), ctx.N, ctx.D, ctx.W,
                                                            ctx.H, ptr(ctx.trec), ptr(ctx.vcT), ptr(ctx.vacc), None),
                                           "gsl_tiny_gather"), "gather")
-    _expect_hip_refusal(lambda: ctx._project_bwd(full), "project bwd")
+    if gather == "fused":
+        with pytest.raises(RuntimeError, match=r"gsl_tiny_project_bwd failed: HIP launch error \(status -3\)"):
+            ctx._project_bwd(full)
+    else:
+        with pytest.raises(RuntimeError, match=r"gsl_fused_project_bwd failed: HIP launch error \(status -3\)"):
+            ctx._project_bwd(full)
 
 
 def test_tracker_kernel_calls_marshal():
