@@ -382,7 +382,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",  # the frame (N Gaussians, one image) is fixed; more GPUs split its tile rows
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
