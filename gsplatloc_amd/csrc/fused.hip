@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_fraster_fwd(
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ FStage<D> sb;
-  int tile = ty0 * tile_w + blockIdx.x;
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) GSL_BWD_ATTR void k_fraster_bwd(
     float* __restrict__ vacc) {
   __shared__ FStageB<D> sb;
   __shared__ int s_final[4];
-  int tile = ty0 * tile_w + blockIdx.x;
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;

@@ -101,6 +101,21 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
 #endif
 #define GSL_Q(arr, g) (arr)[(g) * GSL_QS]
 
+// Workgroup -> tile of the compositing kernels.  The dispatcher deals consecutive workgroups to the 8 XCDs in turn,
+// and every XCD has its own L2, so with the identity map (measured layout) the four tiles a splat overlaps are
+// gathered into up to four L2s.  Build variant -DGSL_XCD_REMAP: XCD x (workgroups x, x+8, x+16, ...) walks ONE
+// contiguous span of the strip's tiles, so neighbouring tiles share an L2.  A bijection of [0, n) for any n.
+#ifdef GSL_XCD_REMAP
+__device__ __forceinline__ int tile_of_block(int b, int n) {
+  int x = b & 7, k = b >> 3;
+  int q = n >> 3, rem = n & 7;
+  return x * q + (x < rem ? x : rem) + k;  // spans of q (+1 for the first n%8 XCDs) tiles
+}
+#define GSL_TILE_OF_BLOCK() tile_of_block((int)blockIdx.x, (int)gridDim.x)
+#else
+#define GSL_TILE_OF_BLOCK() blockIdx.x
+#endif
+
 // DPP lane exchange (no LDS traffic).  Lanes a row_mask disables contribute 0.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_get(float v) {

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ PStage<D> sb;
-  int tile = ty0 * tile_w + blockIdx.x;
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_praster_bwd(
   __shared__ __attribute__((aligned(16))) unsigned char sraw[sizeof(PStageB<D, D>) > sizeof(PStageB<D, 1>)
                                                                  ? sizeof(PStageB<D, D>) : sizeof(PStageB<D, 1>)];
   __shared__ int s_final[4];
-  int tile = ty0 * tile_w + blockIdx.x;
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ TStage<D> sb;
   __shared__ int s_final[4];
-  int tile = ty0 * tile_w + blockIdx.x;
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;

@@ -24,8 +24,10 @@ GSLOC_EXPERIMENTAL=1 timeout -k 10 600 python -m pytest tests/test_gpu_experimen
   run_bench default_s1 &&
   GSLOC_AOS=1 run_bench aos_s1 &&
   GSLOC_LIB_VARIANT=occ5 run_bench occ5_s1 &&
+  GSLOC_LIB_VARIANT=xcd run_bench xcd_s1 &&
   run_bench default_s0_raster --sigma-px 0 --order raster &&
   GSLOC_TINY_GATHER=4 run_bench gather4_s0_raster --sigma-px 0 --order raster &&
   GSLOC_TINY_FUSED=1 run_bench fusedgather_s0_raster --sigma-px 0 --order raster &&
+  GSLOC_LIB_VARIANT=xcd run_bench xcd_s0_raster --sigma-px 0 --order raster &&
   GSLOC_AOS=1 run_bench aos_s0_random --sigma-px 0 --order random &&
   run_bench default_s0_random --sigma-px 0 --order random

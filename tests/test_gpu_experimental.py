@@ -58,6 +58,8 @@ def _run(tmp_path, tag, sigma, env):
     (0.0, {"GSLOC_AOS": "1", "GSLOC_TINY_GATHER": "4"}, {"tiny": True, "stride": 4}),
     (1.0, {"GSLOC_LIB_VARIANT": "occ5"}, {"tiny": False, "stride": 1}),
     (0.0, {"GSLOC_TINY_FUSED": "1"}, {"tiny": True, "stride": 1}),
+    (1.0, {"GSLOC_LIB_VARIANT": "xcd"}, {"tiny": False, "stride": 1}),
+    (0.0, {"GSLOC_LIB_VARIANT": "xcd"}, {"tiny": True, "stride": 1}),
 ])
 def test_experimental_path_matches_default(tmp_path, sigma, env, expect):
     base = _run(tmp_path, "base", sigma, {"GSLOC_AOS": "0", "GSLOC_TINY_GATHER": "16", "GSLOC_LIB_VARIANT": "", "GSLOC_TINY_FUSED": "0"})
