@@ -130,3 +130,34 @@ def test_float32_build_tracks_the_float64_build():
     assert bad.mean() < 3e-3  # threshold-sitting pixels (alpha < 1/255, T <= 1e-4) flip between precisions
     gh, gl = hi["v_viewmat"][:3], lo["v_viewmat"][:3]
     assert np.abs(gl - gh).max() < 2e-3 * np.abs(gh).max()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_binning_agrees_on_adversarial_inputs(seed):
+    """Tile rectangles, counts, keys and offsets of the two oracles on inputs chosen to sit on the clamps: centres
+    outside the image on every side, radii from 1 px to larger than the image, exact tile boundaries, equal depths."""
+    lib = C.load("f64")
+    g = torch.Generator().manual_seed(100 + seed)
+    N, W, H, ts = 400, 150 + 7 * seed, 90 + 5 * seed, 16
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    m2 = torch.stack([torch.rand(N, generator=g, dtype=torch.float64) * (W + 120) - 60,
+                      torch.rand(N, generator=g, dtype=torch.float64) * (H + 120) - 60], -1)
+    m2[:40] = torch.round(m2[:40] / ts) * ts                      # centres exactly on tile boundaries
+    radii = torch.randint(1, 40, (N,), generator=g, dtype=torch.int32)
+    radii[40:50] = 400                                            # wider than the image
+    radii[50:70] = 0                                              # culled
+    dep = torch.rand(N, generator=g, dtype=torch.float64) * 5 + 0.5
+    dep[70:90] = dep[70]                                          # ties resolve by Gaussian id
+    tpg, ids, fids = G.isect_tiles(m2[None], radii[None], dep[None], ts, tw, th)
+    offs = G.isect_offset_encode(ids, 1, tw, th)
+    a = [np.ascontiguousarray(x.numpy()) for x in (m2, radii, dep)]
+    tp = np.zeros(N, np.int32)
+    total = lib.gso_isect(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, N, ts, tw, th, tp.ctypes.data, 0, None,
+                          None, None)
+    assert total == fids.numel() and (tp == tpg[0].numpy()).all()
+    my_ids, my_f, my_o = np.zeros(total, np.int64), np.zeros(total, np.int32), np.zeros(tw * th, np.int32)
+    assert lib.gso_isect(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, N, ts, tw, th, None, total,
+                         my_ids.ctypes.data, my_f.ctypes.data, my_o.ctypes.data) == total
+    assert (my_f == fids.numpy()).all() and (my_ids == ids.numpy()).all() and (my_o == offs.reshape(-1).numpy()).all()
+    assert lib.gso_isect(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, N, ts, tw, th, None, total - 1,
+                         my_ids.ctypes.data, my_f.ctypes.data, my_o.ctypes.data) == -1  # capacity too small
