@@ -97,3 +97,29 @@ def test_legacy_pair_on_the_gpu():
     (rc[0] * w).sum().backward()
     assert float((V1.grad - V2.grad).abs().max()) < 1e-4 * float(V2.grad.abs().max())
     assert float((m1.grad - m2.grad).abs().max()) < 1e-4 * float(m2.grad.abs().max())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hip_binning_on_adversarial_inputs(seed):
+    """The HIP tile binning (stage operators) on the inputs of tests/test_c_oracle.py's adversarial case: centres
+    outside the image, radii larger than the image, exact tile boundaries, equal depths.  Bit-exact against the
+    oracle.  (New in the round without GPU access: first run pending.)"""
+    import gsplatloc_amd as A
+    from oracle import gsplat_oracle as G
+
+    g = torch.Generator().manual_seed(100 + seed)
+    N, W, H, ts = 400, 150 + 7 * seed, 90 + 5 * seed, 16
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    m2 = torch.stack([torch.rand(N, generator=g) * (W + 120) - 60, torch.rand(N, generator=g) * (H + 120) - 60], -1)
+    m2[:40] = torch.round(m2[:40] / ts) * ts
+    radii = torch.randint(1, 40, (N,), generator=g, dtype=torch.int32)
+    radii[40:50] = 400
+    radii[50:70] = 0
+    dep = torch.rand(N, generator=g) * 5 + 0.5
+    dep[70:90] = dep[70]
+    tpg, ids, fids = G.isect_tiles(m2[None], radii[None], dep[None], ts, tw, th)
+    offs = G.isect_offset_encode(ids, 1, tw, th)
+    t2, i2, f2 = A.isect_tiles(m2[None].cuda(), radii[None].cuda(), dep[None].cuda(), ts, tw, th)
+    o2 = A.isect_offset_encode(i2, 1, tw, th)
+    assert torch.equal(t2.cpu(), tpg) and torch.equal(i2.cpu(), ids) and torch.equal(f2.cpu(), fids)
+    assert torch.equal(o2.cpu(), offs)
