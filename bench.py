@@ -366,7 +366,6 @@ def main():
             stage_ms = {}
 
     if rank == 0:
-        I_all = n_total if world == 1 else None
         P = W * H
         bytes_stage = algorithmic_bytes(n_local, n_total, P if world == 1 else (rows[1] - rows[0]) * 16 * W, 4,
                                         ctx.n_tiles, full)
