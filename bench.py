@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=1_000_000,
+                    help="(--n is an ambiguous prefix for torch.distributed.run's own parser: use --gaussians there)")
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=680)
     ap.add_argument("--sigma-px", type=float, default=1.0)
