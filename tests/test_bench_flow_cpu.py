@@ -53,3 +53,18 @@ def test_two_ranks_as_the_harness_launches_them():
     assert d["cpu_baseline"] is None and "2 screen-tile strips" in d["config"]["parallelism"]
     rows = d["config"]["tile_rows_rank0"]
     assert rows[0] == 0 and 0 < rows[1] < 15  # rank 0 owns the top strip of the 15 tile rows
+
+
+def test_failing_side_measurements_do_not_cost_the_headline_line():
+    """Without a GPU the tracker and variant side measurements must fail -- and be reported as errors inside the
+    line, next to a real cpu_baseline (the C oracle runs on the host)."""
+    args = ["--gaussians", "20000", "--width", "320", "--height", "240", "--steps", "3", "--warmup", "1", "--no-graph"]
+    res = subprocess.run([sys.executable, FAKE] + args, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = _check(lines[0], 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "Gaussians/s" and cb["value"] > 0 and cb["cores"] >= 1
+    assert "gsplat_oracle.c" in cb["sample"] and "N=20000" in cb["sample"]
+    assert "error" in d["pose_opt"] and all("error" in v for v in d["variants"]) and len(d["variants"]) == 3
