@@ -190,3 +190,61 @@ def test_sequence_evaluation_cli_on_host_tensors(tmp_path, monkeypatch, capsys):
     rep = json.loads(out.read_text())["room0"]["gsplatloc_amd"]
     assert rep["frames"] == 2 and set(rep) >= {"ATE", "AAE", "frames_with_result", "mean_steps", "seconds"}
     assert "room0" in capsys.readouterr().out
+
+
+GROUP_RANK = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import gsplatloc_amd.context as CX
+import gsplatloc_amd.graph_tracker as GT
+from gsplatloc_amd.my_gsplat import TrackerConfig
+from gsplatloc_amd.my_gsplat.geometry import depth_to_points
+from gsplatloc_amd.synthetic import frame_pair
+
+calls = []
+def refused(status, what):
+    calls.append(what)
+    assert status in (0, -3), (what, status)
+class _Stream:
+    def __init__(self, *a, **k): pass
+CX.current_stream = GT.current_stream = lambda: None
+CX.check = GT.check = refused
+torch.cuda.Stream = _Stream
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H = 64, 48
+fp = frame_pair(W, H, rot_deg=0.3, trans=0.01)
+pts = depth_to_points(fp["depth0"], fp["K"])
+rows = [(0, 2), (2, 3)][rank]                       # 3 tile rows split over the two ranks
+gt = GT.GraphTracker(pts.shape[0], W, H, TrackerConfig(max_steps=5), device="cpu", rows=rows, group=dist.group.WORLD)
+assert gt.render_rows == [(0, 3), (1, 3)][rank]      # one halo tile row towards the neighbour
+gt.load_frame(pts, fp["rgb"], torch.full((pts.shape[0], 3), 0.01), fp["depth1"], fp["c2w0"], fp["c2w1"], fp["K"])
+gt.rc.v_viewmat.fill_(float(rank + 1))               # what this rank's backward would have produced
+gt.partials.fill_(0.5)
+gt._iteration()
+assert calls[-1] == "gsl_pose_step" and "gsl_tracking_loss" in calls
+assert torch.all(gt.reduce_buf[:12] == 3.0), gt.reduce_buf        # 1 + 2: the pose gradient of both strips
+sums = [torch.zeros(2) for _ in range(world)]
+dist.all_gather(sums, gt.partials.view(-1, 2).sum(0))
+assert torch.allclose(gt.reduce_buf[12:14], sums[0] + sums[1])    # loss sums of both strips
+print(f"rank {rank} ok", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_graph_tracker_group_mode_over_gloo(tmp_path):
+    """GraphTracker with rows= / group= on two gloo ranks (launches refused): strip bookkeeping, the single
+    16-float all-reduce and the shared pose step are reached on both ranks with identical reduced values."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "group_rank.py"
+    script.write_text(GROUP_RANK)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", str(script), root]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
