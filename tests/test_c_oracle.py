@@ -161,3 +161,31 @@ def test_binning_agrees_on_adversarial_inputs(seed):
     assert (my_f == fids.numpy()).all() and (my_ids == ids.numpy()).all() and (my_o == offs.reshape(-1).numpy()).all()
     assert lib.gso_isect(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, N, ts, tw, th, None, total - 1,
                          my_ids.ctypes.data, my_f.ctypes.data, my_o.ctypes.data) == -1  # capacity too small
+
+
+def test_frustum_clamp_branches_and_culling_agree():
+    """Gaussians centred outside 1.3x the field of view but large enough to reach the image exercise the clamped
+    branch of the EWA Jacobian and its vjp; others sit behind the camera, beyond the far plane or below
+    radius_clip.  Both oracles must cull the same set and agree on every gradient."""
+    from tests.scenes import frustum_clamp_scene
+
+    sc = frustum_clamp_scene()
+    W, H, V, K, kw = sc["W"], sc["H"], sc["V"], sc["K"], sc["kw"]
+    tanx, tany = sc["tan"]
+    ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "rgbs")]
+    Vg = V.clone().requires_grad_()
+    rc, ra, meta = G.rasterization(*ins, Vg[None], K[None], W, H, render_mode="RGB+D", **kw)
+    radii = meta["radii"][0]
+    assert (radii[12:] == 0).all() and (radii[:12] > 0).sum() >= 8      # the three special ones are culled
+    mc = sc["means"] @ V[:3, :3].T + V[:3, 3]
+    clamped = ((mc[:, 0] / mc[:, 2]).abs() > 1.3 * tanx) | ((mc[:, 1] / mc[:, 2]).abs() > 1.3 * tany)
+    assert int((clamped[:12] & (radii[:12] > 0)).sum()) >= 3             # the clamped branch is really taken
+    ((rc[0] * sc["v_render"]).sum() + (ra[0, ..., 0] * sc["v_alphas"]).sum()).backward()
+    out = C.rasterization(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["rgbs"], V, K, W, H,
+                          render_mode="RGB+D", v_render=sc["v_render"], v_alphas=sc["v_alphas"], threads=2, **kw)
+    np.testing.assert_allclose(out["render"], rc[0].detach().numpy(), rtol=1e-10, atol=1e-12)
+    for name, got, want in (("means", out["v_means"], ins[0].grad), ("quats", out["v_quats"], ins[1].grad),
+                            ("scales", out["v_scales"], ins[2].grad), ("opacities", out["v_opacities"], ins[3].grad),
+                            ("colors", out["v_colors"], ins[4].grad), ("viewmat", out["v_viewmat"][:3], Vg.grad[:3])):
+        want = want.numpy()
+        assert np.abs(got - want).max() <= 1e-9 * max(np.abs(want).max(), 1e-30), name

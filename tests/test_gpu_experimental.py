@@ -123,3 +123,31 @@ def test_hip_binning_on_adversarial_inputs(seed):
     o2 = A.isect_offset_encode(i2, 1, tw, th)
     assert torch.equal(t2.cpu(), tpg) and torch.equal(i2.cpu(), ids) and torch.equal(f2.cpu(), fids)
     assert torch.equal(o2.cpu(), offs)
+
+
+def test_hip_frustum_clamp_branches():
+    """The clamped branch of the EWA Jacobian (centres beyond 1.3x the half field of view) and the near / far /
+    radius_clip culls through the HIP path, against the float64 oracle.  (First run pending.)"""
+    import gsplatloc_amd as A
+    from oracle import gsplat_oracle as G
+    from tests.scenes import frustum_clamp_scene
+
+    sc = frustum_clamp_scene()
+    W, H, kw = sc["W"], sc["H"], sc["kw"]
+    ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "rgbs")]
+    Vo = sc["V"].clone().requires_grad_()
+    ro, ao, mo = G.rasterization(*ins, Vo[None], sc["K"][None], W, H, render_mode="RGB+D", **kw)
+    ((ro[0] * sc["v_render"]).sum() + (ao[0, ..., 0] * sc["v_alphas"]).sum()).backward()
+    gin = [sc[k].float().cuda().requires_grad_() for k in ("means", "quats", "scales", "opacities", "rgbs")]
+    Vg = sc["V"].float().cuda().requires_grad_()
+    rg, ag, mg = A.rasterization(*gin, viewmats=Vg[None], Ks=sc["K"].float().cuda()[None], width=W, height=H,
+                                 render_mode="RGB+D", packed=False, **kw)
+    assert torch.equal(mg["radii"][0].cpu(), mo["radii"][0])
+    ((rg[0] * sc["v_render"].float().cuda()).sum() + (ag[0, ..., 0] * sc["v_alphas"].float().cuda()).sum()).backward()
+    bad = (rg[0].cpu().double() - ro[0].detach()).abs() > 2e-5 + 1e-4 * ro[0].detach().abs()
+    assert float(bad.double().mean()) < 3e-3
+    for got, want in zip(gin + [Vg], ins + [Vo]):
+        a, b = got.grad.cpu().double(), want.grad
+        if a.shape == (4, 4):
+            a, b = a[:3], b[:3]
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-9
