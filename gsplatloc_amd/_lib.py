@@ -14,7 +14,8 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# Build variants (csrc/Makefile: aos = interleaved 64-byte records, occ5 = backward at 5 waves/SIMD) are loaded only
+# Build variants (csrc/Makefile: aos = interleaved 64-byte records, occ5 = backward at 5 waves/SIMD, xcd = one tile span
+# per XCD) are loaded only
 # on request -- GSLOC_LIB_VARIANT=<name>, or GSLOC_AOS=1 for "aos"; default: the measured library
 _VARIANT = os.environ.get("GSLOC_LIB_VARIANT", "aos" if os.environ.get("GSLOC_AOS") == "1" else "")
 _VARIANT = f"_{_VARIANT}" if _VARIANT else ""
