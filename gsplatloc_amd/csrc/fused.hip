@@ -540,11 +540,19 @@ __device__ __forceinline__ void fraster_bwd_body(
           vals[h * AC + 5] = vism * v_alpha;
         }
         if (slot[0] < 0) break;  // nothing left in this chunk for this quadrant
+#if defined(GSL_ABLATE) && GSL_ABLATE >= 3
+        float r = vals[0] + vals[9] + vals[19] + vals[29];  // timing ablation: no cross-lane reduction (results wrong)
+#else
         float r = reduce_scatter32(vals, lane);
+#endif
         int sl = -1;
 #pragma unroll
         for (int hh = 0; hh < G; ++hh) sl = sel64i(hmask[hh], slot[hh], sl);
+#if defined(GSL_ABLATE) && GSL_ABLATE >= 2
+        if (writer && sl >= 0) sb.acc[sl * AP + rk] = r;  // timing ablation: plain LDS store (results wrong)
+#else
         if (writer && sl >= 0) atomicAdd(&sb.acc[sl * AP + rk], r);
+#endif
       }
     }
     __syncthreads();
@@ -565,7 +573,11 @@ __device__ __forceinline__ void fraster_bwd_body(
         if (gi < cnt && f < A) {
           int sl = sb.list[wv][gi];
           size_t g = (size_t)sb.id[sl];
+#if defined(GSL_ABLATE) && (GSL_ABLATE == 1 || GSL_ABLATE >= 3)
+          vacc[g * 16 + f] = sb.acc[sl * AP + f];  // timing ablation: plain global store (results wrong)
+#else
           atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+#endif
         }
       }
     }

@@ -4,9 +4,9 @@
 trainer code runs on it unchanged.  The nerfview viewer hook is not part of the path and is left out.
 
 Differences that do not change results:
-* both pose parameters live in ONE Adam with two parameter groups (own learning rate and L2 weight decay
-  each) instead of two Adam objects -- Adam is element-wise, so the updates are identical, and
-  ``optimizers`` stays a list for the schedulers built over it (gs_trainer_total.py:65-72);
+* ``optimizers`` is the reference's list of two Adam objects (quaternion first, translation second:
+  model.py:93-116), so the scheduler construction over ``optimizers[0]`` / ``optimizers[1]``
+  (gs_trainer_total.py:65-72) runs unchanged;
 * the activated opacities and the concatenated SH coefficients are constants of a frame: GSModel builds
   them once and rebuilds only if ``opacities`` / ``sh0`` / ``shN`` were replaced or modified in place
   (the reference re-runs sigmoid and cat on every iteration).
@@ -80,11 +80,10 @@ class CameraOptModule_quat_tans(nn.Module):
     # ---- optimiser
     def _create_optimizers(self) -> List[Optimizer]:
         cfg = self.config
-        groups = [
-            {"params": [self.quat_cur], "lr": cfg.quat_lr, "weight_decay": cfg.quat_opt_reg, "name": "quat"},
-            {"params": [self.t_cur], "lr": cfg.trans_lr, "weight_decay": cfg.trans_opt_reg, "name": "trans"},
+        return [
+            Adam([{"params": [self.quat_cur], "lr": cfg.quat_lr, "name": "quat"}], weight_decay=cfg.quat_opt_reg),
+            Adam([{"params": [self.t_cur], "lr": cfg.trans_lr, "name": "trans"}], weight_decay=cfg.trans_opt_reg),
         ]
-        return [Adam(groups)]
 
     def optimizer_step(self) -> None:
         for opt in self.optimizers:

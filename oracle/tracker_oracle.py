@@ -191,12 +191,48 @@ def gs_forward(means, quats, scales, opacities, sh, c2w, K, W, H, render_mode="R
     )
 
 
+class _CRasterize(torch.autograd.Function):
+    """The rasterizer call of ``gs_forward`` through the C restatement (oracle/csrc/gsplat_oracle.c, float64)
+    instead of the autograd oracle: same arithmetic (tests/test_c_oracle.py pins one against the other), fast
+    enough for BASELINE.json's frame sizes.  Differentiable in the view matrix only -- all the tracker needs."""
+
+    @staticmethod
+    def forward(ctx, viewmat, means, quats, scales, opacities, sh, K, W, H, threads):
+        from . import c_oracle
+
+        ctx.args = (means, quats, scales, opacities, sh, K, W, H, threads)
+        ctx.save_for_backward(viewmat)
+        out = c_oracle.rasterization(means, quats, scales, opacities, sh, viewmat, K, W, H, sh_degree=1,
+                                     render_mode="RGB+ED", precision="f64", threads=threads)
+        return torch.from_numpy(out["render"])[None], torch.from_numpy(out["alphas"])[None, ..., None]
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas):
+        from . import c_oracle
+
+        means, quats, scales, opacities, sh, K, W, H, threads = ctx.args
+        (viewmat,) = ctx.saved_tensors
+        out = c_oracle.rasterization(means, quats, scales, opacities, sh, viewmat, K, W, H, sh_degree=1,
+                                     render_mode="RGB+ED", v_render=v_render[0], v_alphas=v_alphas[0, ..., 0],
+                                     precision="f64", threads=threads)
+        return (torch.from_numpy(out["v_viewmat"]),) + (None,) * 9
+
+
+def gs_forward_c(means, quats, scales, opacities, sh, c2w, K, W, H, threads=None):
+    """``gs_forward`` (RGB+ED) with the C restatement as the rasterizer; float64, gradient to ``c2w`` only."""
+    render, alphas = _CRasterize.apply(torch.linalg.inv(c2w), means, quats, scales, opacities, sh, K, W, H, threads)
+    return render, alphas, {}
+
+
 def track_frame(
     means: Tensor, scales: Tensor, rgbs: Tensor, depth_gt: Tensor, K: Tensor, W: int, H: int,
     init_c2w: Tensor, gt_c2w: Tensor, max_steps: int = 200, patience: int = 200, min_step: int = 100,
     quat_lr: float = 5e-4, trans_lr: float = 1e-3, wd: float = 1e-3, verbose: bool = False,
+    engine: str = "autograd", threads: Optional[int] = None, stop_after: Optional[int] = None,
 ) -> TrackResult:
-    """Runner.train's per-frame body, gs_trainer_total.py:53-267."""
+    """Runner.train's per-frame body, gs_trainer_total.py:53-267.  ``engine="c"`` renders through the C
+    restatement (full-size frames); ``stop_after`` ends the loop early without touching the schedule
+    (gamma still follows ``max_steps``), for comparing the first iterations of a long run."""
     N = means.shape[0]
     dt = means.dtype
     quats = torch.tensor([1.0, 0, 0, 0], dtype=dt).repeat(N, 1)
@@ -215,7 +251,10 @@ def track_frame(
         opt_q.zero_grad(set_to_none=True)
         opt_t.zero_grad(set_to_none=True)
         c2w = camera_forward(q, t)
-        renders, _, _ = gs_forward(means, quats, scales, opac, sh, c2w, K, W, H)
+        if engine == "c":
+            renders, _, _ = gs_forward_c(means, quats, scales, opac, sh, c2w, K, W, H, threads)
+        else:
+            renders, _, _ = gs_forward(means, quats, scales, opac, sh, c2w, K, W, H)
         depths = renders[..., 3:4]
         total, dl, sl = tracking_loss(depths, depth_gt)
         total.backward()
@@ -233,7 +272,7 @@ def track_frame(
             print(f"step {step} loss {lv:.6e} eT {eT:.3e} eR {eR:.3e}")
         res.steps = step + 1
         res.final_c2w = c2w.detach().clone()
-        if counter >= patience:
+        if counter >= patience or (stop_after is not None and step + 1 >= stop_after):
             break
         opt_q.step()
         opt_t.step()

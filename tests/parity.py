@@ -1,0 +1,45 @@
+"""Flip-aware comparison helpers shared by the GPU parity tests (no oracle code here).
+
+The compositing loop takes discrete decisions per (pixel, splat): skip when alpha < 1/255, stop when the next
+transmittance would be <= 1e-4, and a Gaussian's tile rectangle follows ceil() of its radius.  A float32 run and
+the float64 oracle can disagree on such a decision for a pixel that sits on a threshold; the rendered value of
+that pixel then differs by far more than rounding, and so does its contribution to every gradient.  These pixels
+are a property of the comparison, not of either implementation, so the gradient tests
+
+  1. render with both sides,
+  2. call a pixel "agreeing" when every channel and alpha match within the image tolerance
+     (north_star: 1e-4 relative; a small absolute floor for values near zero),
+  3. zero the upstream gradient of the disagreeing pixels ON BOTH SIDES,
+  4. compare the gradients of the agreeing pixels at north_star's 1e-4 of the largest entry,
+
+and report (and bound) the disagreeing fraction separately.
+"""
+import torch
+
+IMAGE_RTOL = 1e-4   # north_star: rendered depth within 1e-4 relative
+IMAGE_ATOL = 2e-5   # floor for channels near zero (colours / alpha are O(1), depths O(1..5))
+POSE_GRAD_TOL = 1e-4  # north_star: pose gradient within 1e-4 relative (of the largest entry)
+
+
+def agreeing_pixels(render_a, alpha_a, render_b, alpha_b, rtol=IMAGE_RTOL, atol=IMAGE_ATOL):
+    """[..., H, W] bool: pixels whose channels and alpha agree within tolerance.  Inputs [...,H,W,D] / [...,H,W,1]."""
+    ra, rb = torch.as_tensor(render_a).detach().cpu().double(), torch.as_tensor(render_b).detach().cpu().double()
+    aa, ab = torch.as_tensor(alpha_a).detach().cpu().double(), torch.as_tensor(alpha_b).detach().cpu().double()
+    if aa.dim() == ra.dim() - 1:
+        aa, ab = aa[..., None], ab[..., None]
+    ok = ((ra - rb).abs() <= atol + rtol * rb.abs()).all(-1)
+    ok &= ((aa - ab).abs() <= atol + rtol * ab.abs()).all(-1)
+    return ok
+
+
+def rel_inf(a, b):
+    """max |a - b| / max |b|."""
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-300))
+
+
+def report(tag, flipped_frac, **errs):
+    msg = f"[parity] {tag}: flipped pixels {flipped_frac:.2e}" + "".join(f", {k} {v:.2e}" for k, v in errs.items())
+    print(msg)
+    return msg

@@ -1,0 +1,163 @@
+"""Parity at BASELINE.json's configurations, full size, on the GPU (configs[1..4]; configs[0] is the CPU ICP case,
+tests/test_icp_baseline.py):
+
+  S  Replica room0-like frame pair: ~100k Gaussians, 640x480, 200 pose-optimisation iterations (GraphTracker)
+  T  TUM fr1/desk-like frame: one Gaussian per pixel of a 640x480 depth frame (~300k) with invalid (zero) depths
+  R  1 M Gaussians, 1200x680 (the bench headline, random order sigma_px = 1, and the depth-frame regime)
+  X  5 M random Gaussians, 1920x1080
+
+Checker: the float64 C restatement (oracle/csrc/gsplat_oracle.c), which finishes these sizes in seconds.
+Tolerances: images 1e-4 relative (+2e-5 absolute), pose gradient 1e-4 of its largest entry, both as north_star
+states them; the gradient comparison is flip-aware (tests/parity.py) and the flipped-pixel fraction is bounded.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.parity import POSE_GRAD_TOL, agreeing_pixels, rel_inf, report
+
+pytestmark = pytest.mark.gpu
+THREADS = min(os.cpu_count() or 1, 16)
+
+
+def _context_vs_c_oracle(tag, sc, V, W, H, v, max_flipped, grad_names=("means", "scales", "opacities")):
+    """RenderContext forward + backward against the C oracle on the same inputs; returns the error report."""
+    from gsplatloc_amd.context import RenderContext
+    from oracle import c_oracle as C
+
+    dev = torch.device("cuda")
+    N = sc["means"].shape[0]
+    cpu = [sc[k] for k in ("means", "quats", "scales", "opacities", "sh")]
+    want_f = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", precision="f64", threads=THREADS)
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    inp = tuple(t.to(dev).contiguous() for t in cpu) + (V.to(dev).contiguous(), sc["K"].to(dev).contiguous())
+    n_is = ctx.calibrate(*inp)
+    render, alphas = ctx.forward(*inp)
+    torch.cuda.synchronize()
+    assert abs(n_is - want_f["n_isects"]) <= max(8, int(2e-6 * n_is)), (n_is, want_f["n_isects"])  # ceil() borderlines
+    ok = agreeing_pixels(render, alphas, torch.from_numpy(want_f["render"]), torch.from_numpy(want_f["alphas"])[..., None])
+    flipped = 1.0 - ok.double().mean().item()
+    assert flipped < max_flipped, f"{tag}: {flipped:.2e} of the pixels disagree with the oracle"
+    depth_g, depth_o = render[..., 3].cpu().double()[ok], torch.from_numpy(want_f["render"][..., 3])[ok]
+    valid = depth_o > 0
+    depth_rel = float(((depth_g - depth_o).abs()[valid] / depth_o[valid]).max())
+    alpha_abs = float((alphas[..., 0].cpu().double()[ok] - torch.from_numpy(want_f["alphas"])[ok]).abs().max())
+    vm = v * ok[..., None]
+    want = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f64",
+                           threads=THREADS)
+    grads = ctx.backward(vm.float().to(dev).contiguous(), torch.zeros(H, W, 1, device=dev), full=True)
+    torch.cuda.synchronize()
+    ctx.check_capacity()
+    pose_err = rel_inf(grads["viewmat"][:3], want["v_viewmat"][:3])
+    errs = dict(depth_rel=depth_rel, alpha_abs=alpha_abs, v_viewmat=pose_err)
+    for name in grad_names:
+        a, b = grads[name].cpu().double().numpy().reshape(-1), want["v_" + name].reshape(-1)
+        errs["v_" + name] = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    report(tag, flipped, **errs)
+    assert depth_rel < 1e-4 + 2e-5 and alpha_abs < 1e-4 + 2e-5
+    assert pose_err < POSE_GRAD_TOL, f"{tag}: pose gradient {pose_err:.2e}"
+    for name in grad_names:
+        assert errs["v_" + name] < 1e-4, (tag, name, errs["v_" + name])
+    return errs
+
+
+def _depth_upstream(H, W, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.zeros(H, W, 4, dtype=torch.float64)
+    v[..., 3] = torch.randn(H, W, generator=g, dtype=torch.float64)
+    return v
+
+
+@pytest.mark.parametrize("N,W,H,sigma_px,order,max_flipped", [
+    (1_000_000, 1200, 680, 1.0, "random", 5e-3),    # workload R, the bench headline
+    (1_000_000, 1200, 680, 0.0, "raster", 5e-3),    # R in the reference's regime (as-coded scales, depth-frame order)
+    (5_000_000, 1920, 1080, 1.0, "random", 5e-3),   # workload X of BASELINE.json configs[4]
+])
+def test_config_R_and_X_render_and_gradients_match_the_c_oracle(N, W, H, sigma_px, order, max_flipped):
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    sc = random_scene(N, W, H, sigma_px=sigma_px, order=order)
+    V = torch.linalg.inv(perturbed_pose())
+    _context_vs_c_oracle(f"{'X' if N > 1_000_000 else 'R'} N={N} {W}x{H} sigma={sigma_px} {order}", sc, V, W, H,
+                         _depth_upstream(H, W), max_flipped)
+
+
+def _tum_like_frame(W=640, H=480, hole_frac=0.08, seed=3):
+    """One Gaussian per pixel of a depth frame, with rectangular patches of invalid (zero) depth as a TUM frame
+    has them: depth_to_points leaves those points at the camera origin (/root/reference/src/data/Image.py:29-35,
+    geometry.py:138-161) and the near plane culls them."""
+    from gsplatloc_amd.synthetic import SH_C0, frame_pair
+    from oracle import tracker_oracle as T
+
+    fp = frame_pair(W, H, rot_deg=0.4, trans=0.015, seed=seed)
+    depth = fp["depth0"].clone()
+    g = torch.Generator().manual_seed(seed)
+    n_holes = int(hole_frac * W * H / (24 * 18))
+    for _ in range(n_holes):
+        x0, y0 = int(torch.randint(0, W - 24, (1,), generator=g)), int(torch.randint(0, H - 18, (1,), generator=g))
+        depth[y0:y0 + 18, x0:x0 + 24] = 0.0
+    pts = T.depth_to_points(depth, fp["K"])
+    scales = torch.zeros_like(pts)
+    valid = depth.reshape(-1) > 0
+    scales[valid] = T.init_gs_scales(pts[valid], as_coded=True)  # kNN of the valid points (as-coded: ~1e-5 m)
+    scales[~valid] = 1e-6
+    N = pts.shape[0]
+    sh = torch.zeros(N, 4, 3)
+    sh[:, 0] = (fp["rgb"] - 0.5) / SH_C0
+    sc = dict(means=pts, quats=torch.tensor([1.0, 0, 0, 0]).repeat(N, 1), scales=scales, opacities=torch.ones(N), sh=sh,
+              K=fp["K"])
+    return sc, fp, int(valid.sum())
+
+
+def test_config_T_depth_frame_with_invalid_pixels():
+    sc, fp, n_valid = _tum_like_frame()
+    W, H = 640, 480
+    assert sc["means"].shape[0] == W * H and n_valid < W * H
+    V = torch.linalg.inv(fp["c2w1"])
+    _context_vs_c_oracle(f"T N={W * H} ({n_valid} valid) {W}x{H}", sc, V, W, H, _depth_upstream(H, W, seed=5), 5e-3)
+
+
+def test_config_S_tracker_200_iterations():
+    """GraphTracker on config S against the oracle tracker (C rasterizer, float64): the first iterations step by
+    step, then the whole 200-iteration run through its invariants and its read-outs."""
+    import gsplatloc_amd.my_gsplat as M
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    from gsplatloc_amd.my_gsplat.geometry import depth_to_points
+    from gsplatloc_amd.synthetic import frame_pair
+    from oracle import tracker_oracle as T
+
+    dev = torch.device("cuda")
+    W, H, iters, first = 640, 480, 200, 25
+    fp = frame_pair(W, H, rot_deg=0.3, trans=0.01)
+    K = fp["K"].to(dev)
+    pts0 = depth_to_points(fp["depth0"].to(dev), K)[::3].contiguous()  # 102 400 Gaussians
+    rgb = fp["rgb"].to(dev)[::3].contiguous()
+    assert pts0.shape[0] == 102_400
+    pts1 = depth_to_points(fp["depth1"].to(dev), K)
+    scales = M.init_gs_scales(pts0)
+    src = M.compute_depth_gt(pts1, fp["rgb"].to(dev), K[None], torch.eye(4, device=dev)[None], H, W)
+    cfg = M.TrackerConfig(max_steps=iters, min_step=100, patience=200)
+    gt = GraphTracker(pts0.shape[0], W, H, cfg, device=dev, poll=50)
+    gt.load_frame(pts0, rgb, scales, src, fp["c2w0"].to(dev), fp["c2w1"].to(dev), K)
+    res = gt.run()
+    assert res.steps == iters
+    # the same frame through the oracle tracker for the first iterations (same schedule: gamma follows max_steps)
+    res_o = T.track_frame(pts0.cpu().double(), scales.cpu().double(), rgb.cpu().double(),
+                          src.reshape(1, H, W, 1).cpu().double(), fp["K"].double(), W, H, fp["c2w0"].double(),
+                          fp["c2w1"].double(), max_steps=iters, min_step=100, engine="c", threads=THREADS,
+                          stop_after=first)
+    lg, lo = torch.tensor(res.losses[:first], dtype=torch.float64), torch.tensor(res_o.losses, dtype=torch.float64)
+    rel = ((lg - lo).abs() / lo).max().item()
+    report("S tracker, first %d iterations" % first, 0.0, loss_rel=rel, loss0_rel=abs(float(lg[0] - lo[0]) / float(lo[0])))
+    # iteration 0 has no optimiser history: the loss itself must agree to the image tolerance;
+    # later iterations pass through Adam (g / sqrt(v) amplifies rounding of tiny gradient entries): 1e-3
+    assert abs(float(lg[0] - lo[0])) < 1e-4 * float(lo[0])
+    assert rel < 1e-3, rel
+    # invariants of the full run
+    losses = torch.tensor(res.losses)
+    assert torch.isfinite(losses).all() and float(losses[-20:].mean()) < 0.35 * float(losses[0])
+    e0 = M.calculate_translation_error(fp["c2w0"], fp["c2w1"])
+    assert res.best_eT < 0.1 * e0, (res.best_eT, e0)
+    assert res.best_loss == pytest.approx(float(losses[101:].min()), rel=1e-6)  # min-loss read-out after step 100

@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from oracle import gsplat_oracle as G
+from tests.parity import POSE_GRAD_TOL, agreeing_pixels, report
 from tests.scenes import random_scene, sh_from_rgb, small_pose
 
 pytestmark = pytest.mark.gpu
@@ -188,12 +189,14 @@ def test_rasterize_fwd_bwd(D, opacity, sigma_px):
     gen = torch.Generator().manual_seed(21)
     v_c = torch.randn(rc_o.shape, generator=gen)
     v_a = torch.randn(ra_o.shape, generator=gen)
+    ok = agreeing_pixels(rc_g, ra_g, rc_o, ra_o)  # flip-aware, see tests/parity.py
+    v_c, v_a = v_c * ok[..., None], v_a * ok[..., None]
     ((rc_o * v_c.double()).sum() + (ra_o * v_a.double()).sum()).backward()
     ((rc_g * v_c.to(DEV)).sum() + (ra_g * v_a.to(DEV)).sum()).backward()
     for g_t, o_t, nm in zip(ins_g, ins_o, ("v_means2d", "v_conics", "v_colors", "v_opacities")):
         scale = float(o_t.grad.abs().max())
-        mostly_close(g_t.grad, o_t.grad, rtol=1e-3, atol=2e-4 * scale, max_bad_frac=5e-3, what=nm)
-        assert rel_inf(g_t.grad.sum(1), o_t.grad.sum(1)) < 5e-3, nm + " (summed)"
+        mostly_close(g_t.grad, o_t.grad, rtol=1e-4, atol=1e-5 * scale, max_bad_frac=1e-3, what=nm)
+        assert rel_inf(g_t.grad.sum(1), o_t.grad.sum(1)) < 1e-4, nm + " (summed)"
 
 
 def test_rasterize_empty_and_edge_tiles():
@@ -271,9 +274,14 @@ def test_rasterization_end_to_end(mode, sh, fused, monkeypatch):
         assert k in meta
     gen = torch.Generator().manual_seed(2)
     v = torch.randn(rc_o.shape, generator=gen)
+    # flip-aware (tests/parity.py): pixels whose forward disagrees carry no upstream gradient on either side
+    ok = agreeing_pixels(rc_g, ra_g, rc_o, ra_o)
+    v = v * ok[..., None]
     (rc_o * v.double()).sum().backward()
     (rc_g * v.to(DEV)).sum().backward()
-    assert rel_inf(Vg.grad[0, :3], Vo.grad[0, :3]) < 2e-3, f"v_viewmat {mode}"
+    err = rel_inf(Vg.grad[0, :3], Vo.grad[0, :3])
+    report(f"end-to-end {mode} {fused}", 1.0 - ok.double().mean().item(), v_viewmat=err)
+    assert err < POSE_GRAD_TOL, f"v_viewmat {mode}: {err:.2e}"
 
 
 @pytest.mark.parametrize("mode,sh_deg,aa", [("RGB+ED", 1, False), ("RGB+ED", 3, False), ("RGB", None, False),
@@ -304,16 +312,23 @@ def test_fused_full_gradients(mode, sh_deg, aa):
     mostly_close(ra_g, ra_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="alpha")
     v_c = torch.randn(rc_o.shape, generator=gen)
     v_a = torch.randn(ra_o.shape, generator=gen)
+    # flip-aware (tests/parity.py): threshold-sitting pixels carry no upstream gradient on either side
+    ok = agreeing_pixels(rc_g, ra_g, rc_o, ra_o)
+    v_c, v_a = v_c * ok[..., None], v_a * ok[..., None]
     ((rc_o * v_c.double()).sum() + (ra_o * v_a.double()).sum()).backward()
     ((rc_g * v_c.to(DEV)).sum() + (ra_g * v_a.to(DEV)).sum()).backward()
-    assert rel_inf(ins_g[5].grad[0, :3], ins_o[5].grad[0, :3]) < 2e-3, "v_viewmat"
+    err = rel_inf(ins_g[5].grad[0, :3], ins_o[5].grad[0, :3])
+    report(f"fused full gradients {mode} sh={sh_deg} aa={aa}", 1.0 - ok.double().mean().item(), v_viewmat=err)
+    assert err < POSE_GRAD_TOL, f"v_viewmat: {err:.2e}"
     for g_t, o_t, nm in zip(ins_g[:5], ins_o[:5], names + ("colors",)):
         if o_t.grad is None:
             assert g_t.grad is None or float(g_t.grad.abs().max()) == 0.0, nm
             continue
+        # per-Gaussian gradients: 1e-4 relative with a floor of 1e-5 of the largest entry (float32 sums of
+        # ~50 signed terms cancel: entries far below the largest one carry its rounding noise)
         scale = float(o_t.grad.abs().max())
-        mostly_close(g_t.grad, o_t.grad, rtol=2e-3, atol=5e-4 * scale, max_bad_frac=1e-2, what="v_" + nm)
-        assert rel_inf(g_t.grad.sum(0), o_t.grad.sum(0)) < 1e-2, nm + " (summed)"
+        mostly_close(g_t.grad, o_t.grad, rtol=1e-4, atol=1e-5 * scale, max_bad_frac=1e-3, what="v_" + nm)
+        assert rel_inf(g_t.grad.sum(0), o_t.grad.sum(0)) < 1e-4, nm + " (summed)"
 
 
 def test_fused_tile_strip_matches_full_render():
@@ -382,3 +397,91 @@ def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
         for k in ("means", "scales", "opacities", "colors"):
             scale = float(out["0"][k].abs().max())
             mostly_close(out["1"][k], out["0"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
+
+
+def test_legacy_pair_on_the_gpu():
+    """project_gaussians / rasterize_gaussians (north_star's legacy operator pair, IDX:14774 / 14765) over the HIP
+    stage operators against the fused HIP rasterization; the glue itself is covered on the CPU by
+    tests/test_legacy_cpu.py.  Two float32 kernels with different operation order: images to the image tolerance
+    (a threshold-sitting pixel may differ), gradients flip-aware."""
+    import gsplat
+    from tests.scenes import random_scene, small_pose
+
+    N, W, H = 4000, 200, 150
+    sc = random_scene(N, W, H, seed=5, sigma_px=2.0, aniso=True, opacity=(0.3, 1.0), dtype=torch.float32)
+    V = torch.linalg.inv(small_pose(1.0, 0.03, dtype=torch.float32)).cuda()
+    cu = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in sc.items()}
+    fx, fy, cx, cy = (float(sc["K"][0, 0]), float(sc["K"][1, 1]), float(sc["K"][0, 2]), float(sc["K"][1, 2]))
+    m1, V1 = cu["means"].clone().requires_grad_(), V.clone().requires_grad_()
+    xys, depths, radii, conics, comp, hit, cov3d = gsplat.project_gaussians(
+        m1, cu["scales"], 1.0, cu["quats"], V1, fx, fy, cx, cy, H, W, 16)
+    img, alpha = gsplat.rasterize_gaussians(xys, depths, radii, conics, hit, cu["rgbs"], cu["opacities"][:, None], H, W, 16,
+                                            return_alpha=True)
+    m2, V2 = cu["means"].clone().requires_grad_(), V.clone().requires_grad_()
+    rc, ra, meta = gsplat.rasterization(m2, cu["quats"], cu["scales"], cu["opacities"], cu["rgbs"], V2[None], cu["K"][None],
+                                        W, H, render_mode="RGB")
+    assert torch.equal(radii, meta["radii"][0]) and cov3d.shape == (N, 6)
+    mostly_close(img, rc[0], rtol=1e-4, atol=2e-5, max_bad_frac=1e-3, what="legacy image")
+    mostly_close(alpha, ra[0, ..., 0], rtol=1e-4, atol=2e-5, max_bad_frac=1e-3, what="legacy alpha")
+    ok = agreeing_pixels(img, alpha, rc[0], ra[0]).to("cuda")
+    w = torch.linspace(0.5, 1.5, img.numel(), device="cuda").reshape(img.shape) * ok[..., None]
+    (img * w).sum().backward()
+    (rc[0] * w).sum().backward()
+    assert float((V1.grad - V2.grad).abs().max()) < 1e-4 * float(V2.grad.abs().max())
+    assert float((m1.grad - m2.grad).abs().max()) < 1e-4 * float(m2.grad.abs().max())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hip_binning_on_adversarial_inputs(seed):
+    """The HIP tile binning (stage operators) on the inputs of tests/test_c_oracle.py's adversarial case: centres
+    outside the image, radii larger than the image, exact tile boundaries, equal depths.  Bit-exact against the
+    oracle."""
+    import gsplatloc_amd as A
+    from oracle import gsplat_oracle as G
+
+    g = torch.Generator().manual_seed(100 + seed)
+    N, W, H, ts = 400, 150 + 7 * seed, 90 + 5 * seed, 16
+    tw, th = (W + ts - 1) // ts, (H + ts - 1) // ts
+    m2 = torch.stack([torch.rand(N, generator=g) * (W + 120) - 60, torch.rand(N, generator=g) * (H + 120) - 60], -1)
+    m2[:40] = torch.round(m2[:40] / ts) * ts
+    radii = torch.randint(1, 40, (N,), generator=g, dtype=torch.int32)
+    radii[40:50] = 400
+    radii[50:70] = 0
+    dep = torch.rand(N, generator=g) * 5 + 0.5
+    dep[70:90] = dep[70]
+    tpg, ids, fids = G.isect_tiles(m2[None], radii[None], dep[None], ts, tw, th)
+    offs = G.isect_offset_encode(ids, 1, tw, th)
+    t2, i2, f2 = A.isect_tiles(m2[None].cuda(), radii[None].cuda(), dep[None].cuda(), ts, tw, th)
+    o2 = A.isect_offset_encode(i2, 1, tw, th)
+    assert torch.equal(t2.cpu(), tpg) and torch.equal(i2.cpu(), ids) and torch.equal(f2.cpu(), fids)
+    assert torch.equal(o2.cpu(), offs)
+
+
+def test_hip_frustum_clamp_branches():
+    """The clamped branch of the EWA Jacobian (centres beyond 1.3x the half field of view) and the near / far /
+    radius_clip culls through the HIP path, against the float64 oracle."""
+    import gsplatloc_amd as A
+    from oracle import gsplat_oracle as G
+    from tests.scenes import frustum_clamp_scene
+
+    sc = frustum_clamp_scene()
+    W, H, kw = sc["W"], sc["H"], sc["kw"]
+    ins = [sc[k].clone().requires_grad_() for k in ("means", "quats", "scales", "opacities", "rgbs")]
+    Vo = sc["V"].clone().requires_grad_()
+    ro, ao, mo = G.rasterization(*ins, Vo[None], sc["K"][None], W, H, render_mode="RGB+D", **kw)
+    gin = [sc[k].float().cuda().requires_grad_() for k in ("means", "quats", "scales", "opacities", "rgbs")]
+    Vg = sc["V"].float().cuda().requires_grad_()
+    rg, ag, mg = A.rasterization(*gin, viewmats=Vg[None], Ks=sc["K"].float().cuda()[None], width=W, height=H,
+                                 render_mode="RGB+D", packed=False, **kw)
+    assert torch.equal(mg["radii"][0].cpu(), mo["radii"][0])
+    ok = agreeing_pixels(rg[0], ag[0], ro[0], ao[0])  # flip-aware, tests/parity.py
+    v_r, v_a = sc["v_render"] * ok[..., None], sc["v_alphas"] * ok
+    ((ro[0] * v_r).sum() + (ao[0, ..., 0] * v_a).sum()).backward()
+    ((rg[0] * v_r.float().cuda()).sum() + (ag[0, ..., 0] * v_a.float().cuda()).sum()).backward()
+    bad = (rg[0].cpu().double() - ro[0].detach()).abs() > 2e-5 + 1e-4 * ro[0].detach().abs()
+    assert float(bad.double().mean()) < 3e-3
+    for got, want in zip(gin + [Vg], ins + [Vo]):
+        a, b = got.grad.cpu().double(), want.grad
+        if a.shape == (4, 4):
+            a, b = a[:3], b[:3]
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9

@@ -51,6 +51,27 @@ def test_pose_module_matches_two_adam_restatement():
     assert mod().shape == (4, 4) and torch.equal(mod()[3], torch.tensor([0.0, 0, 0, 1]))
 
 
+def test_pose_module_optimizers_index_like_the_reference_trainer():
+    """gs_trainer_total.py:65-72 builds one ExponentialLR over camera_opt.optimizers[0] and one over
+    camera_opt.optimizers[1]: the module must expose two Adam objects, quaternion first (model.py:93-116)."""
+    cfg = M.CameraConfig()
+    mod = M.CameraOptModule_quat_tans(_pose(5), config=cfg)
+    assert len(mod.optimizers) == 2
+    schedulers = [torch.optim.lr_scheduler.ExponentialLR(mod.optimizers[0], gamma=0.2 ** (1.0 / 200)),
+                  torch.optim.lr_scheduler.ExponentialLR(mod.optimizers[1], gamma=0.2 ** (1.0 / 200))]
+    q_opt, t_opt = mod.optimizers
+    assert q_opt.param_groups[0]["params"][0] is mod.quat_cur and t_opt.param_groups[0]["params"][0] is mod.t_cur
+    assert q_opt.param_groups[0]["lr"] == cfg.quat_lr and q_opt.param_groups[0]["weight_decay"] == cfg.quat_opt_reg
+    assert t_opt.param_groups[0]["lr"] == cfg.trans_lr and t_opt.param_groups[0]["weight_decay"] == cfg.trans_opt_reg
+    assert q_opt.param_groups[0]["name"] == "quat" and t_opt.param_groups[0]["name"] == "trans"
+    mod.optimizer_clean()
+    mod().sum().backward()
+    mod.optimizer_step()
+    for s in schedulers:
+        s.step()
+    assert abs(q_opt.param_groups[0]["lr"] - cfg.quat_lr * 0.2 ** (1.0 / 200)) < 1e-12
+
+
 def test_pose_module_update_and_prediction():
     T0, T1 = _pose(3), _pose(4)
     mod = M.CameraOptModule_quat_tans(T0.clone())
