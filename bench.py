@@ -202,7 +202,13 @@ def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
     dt = (time.perf_counter() - t) / steps
     ctx.check_capacity()
     return {"sigma_px": sigma_px, "order": order, "intersections_per_gaussian": n_is / N, "ms_per_step": dt * 1e3,
-            "gaussians_per_s": N / dt, "backward": "tiny-splat slabs" if ctx.tiny else "wave reduce-scatter"}
+            "gaussians_per_s": N / dt, "backward": backward_name(ctx)}
+
+
+def backward_name(ctx):
+    if ctx.slab:
+        return f"per-pixel walk + {ctx.slab}x{ctx.slab} LDS slabs"
+    return "tiny-splat slabs (global)" if ctx.tiny else "wave reduce-scatter"
 
 
 def pose_opt_rate(dev):
@@ -394,6 +400,7 @@ def main():
                 "strip_intersections_rank0": n_total, "tile_rows_rank0": list(rows), "gaussians_rank0": n_local,
                 "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
                 "launch": "hipGraph replay" if graph is not None else "eager",
+                "backward": backward_name(ctx),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -71,6 +71,8 @@ _SIGNATURES = {
                                      P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                     P, P, P, P, P, P, P, P]),
+    "gsl_slab_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                    P, P, P, P, P, P, P, P]),
     "gsl_debug_reduce_scatter": (c_int, [P, P, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "gsl_isect_offsets": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),

@@ -23,6 +23,7 @@ from .fused import _MODES, MAX_STRIP_TILES, _raster_fn, alloc_records, tile_n_bi
 
 
 TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
+SLAB_RCULL_MAX = 3.999  # ... at most 8 pixel centres per axis (sigma_px <= ~1.1 at opacity 1)
 
 
 class RenderContext:
@@ -75,6 +76,8 @@ class RenderContext:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
         self.capacity = 0
         self.tiny = False
+        self.slab = 0  # box of the slab backward (4 or 8) when every splat is small enough, else 0
+        self.flags = torch.zeros(4, dtype=i32, device=dev)  # [0] slab miss (sticky, set by the kernels)
         # pass 2 of the tiny-splat backward: the measured kernel unless the untested 4-lane variant is asked for
         import os
         self._tiny_gather = (self.lib.gsl_tiny_gather4 if os.environ.get("GSLOC_TINY_GATHER") == "4"
@@ -107,7 +110,15 @@ class RenderContext:
         compositing backward.  GSLOC_TINY=0 disables."""
         import os
         r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
-        want = os.environ.get("GSLOC_TINY", "1") != "0" and r_max < TINY_RCULL_MAX
+        mode = os.environ.get("GSLOC_BWD", "auto")  # auto | general | tiny | slab4 | slab8 (dev switch)
+        self.slab = 0
+        if mode in ("slab4", "slab8"):
+            self.slab = int(mode[-1])
+        elif mode == "auto" and os.environ.get("GSLOC_SLAB", "1") != "0":
+            if TINY_RCULL_MAX <= r_max < SLAB_RCULL_MAX:
+                self.slab = 8
+        want = (not self.slab and mode in ("auto", "tiny") and os.environ.get("GSLOC_TINY", "1") != "0"
+                and r_max < TINY_RCULL_MAX)
         if want and self.trec is None:
             self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
             self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
@@ -121,6 +132,8 @@ class RenderContext:
             raise RuntimeError(f"intersection capacity exceeded ({n} > {self.capacity}); call calibrate() again")
         if self.tiny and float(self.Q1[:, 3].max()) >= TINY_RCULL_MAX:
             raise RuntimeError("a splat outgrew the tiny-splat backward (r_cull >= 2 px); call calibrate() again")
+        if self.slab and int(self.flags[0].item()):
+            raise RuntimeError(f"a splat outgrew the {self.slab}x{self.slab} slab backward; call calibrate() again")
         return n
 
     # ------------------------------------------------------------------ stages (one C-ABI call each)
@@ -148,7 +161,10 @@ class RenderContext:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,
                   self.ty0, self.ty1, ptr(self.offs), ptr(self.flatten_ids), self.capacity, ptr(self.render),
                   ptr(self.alphas), ptr(self.last_ids), ptr(v_render), ptr(v_alphas))
-        if self.tiny:
+        if self.slab:
+            check(self.lib.gsl_slab_raster_bwd(*common[:5], self.slab, *common[5:], ptr(self.vacc), ptr(self.flags),
+                                               current_stream()), "gsl_slab_raster_bwd")
+        elif self.tiny:
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), current_stream()),
                   "gsl_tiny_raster_bwd")
             if not self._tiny_fused:

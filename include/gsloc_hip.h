@@ -192,6 +192,18 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
+/* "Slab" backward for small splats: valid when every r_cull (Q1[:,3]) is < box/2 px (box = 4 or 8), i.e. no splat
+ * reaches more than box x box pixel centres.  Replaces gsl_*_raster_bwd with the same vacc contract (rows are added
+ * to, the projection backward reads and clears them).  Per-pixel walk, per-splat record slabs in LDS, no cross-lane
+ * reduction.  flags (int32[1], may be NULL): flags[0] is set to 1 if a (pixel, splat) pair fell outside its slab,
+ * i.e. the precondition did not hold and the gradients are incomplete -- the caller polls it and falls back. */
+int gsl_slab_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int box,
+                        int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                        const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                        const float* render, const float* alphas, const int32_t* last_ids,
+                        const float* v_render, const float* v_alphas, float* vacc, int32_t* flags,
+                        void* stream);
+
 /* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4
  * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_*_raster_bwd: instead of
  * reducing and accumulating gradient rows it stores per (splat, pixel) records into trec[N][16][2] (zero on
