@@ -76,7 +76,7 @@ def algorithmic_bytes(N, I, P, D, n_tiles, full):
 
 STAGE_KERNELS = {  # stage timer -> kernels it brackets (names as rocprofv3 prints them, template arguments dropped)
     "project_fwd": ("k_fproject<",), "bin": ("k_ftile_scan", "k_fscatter", "k_tile_sort"),
-    "raster_fwd": ("k_praster_fwd", "k_fraster_fwd"), "raster_bwd": ("k_fraster_bwd", "k_praster_bwd", "k_tiny_bwd", "k_tiny_gather"),
+    "raster_fwd": ("k_praster_fwd", "k_fraster_fwd"), "raster_bwd": ("k_mraster_bwd", "k_fraster_bwd", "k_praster_bwd", "k_sraster_bwd", "k_tiny_bwd", "k_tiny_gather"),
     "project_bwd": ("k_fproject_bwd", "k_freduce_viewmat"),
 }
 
@@ -206,9 +206,11 @@ def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
 
 
 def backward_name(ctx):
-    if ctx.slab:
+    if getattr(ctx, "slab", 0):
         return f"per-pixel walk + {ctx.slab}x{ctx.slab} LDS slabs"
-    return "tiny-splat slabs (global)" if ctx.tiny else "wave reduce-scatter"
+    import os
+    kind = os.environ.get("GSLOC_RASTER_BWD", "mfma")
+    return "tiny-splat slabs (global)" if getattr(ctx, "tiny", False) else {"mfma": "quadrant walk + MFMA pixel sums", "quad": "quadrant walk + wave reduce-scatter", "px": "per-pixel two-phase"}[kind]
 
 
 def pose_opt_rate(dev):

@@ -49,6 +49,8 @@ _SIGNATURES = {
                                      P, P, P, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                      P, P, P, P, P, P, P]),
+    "gsl_mfma_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                    P, P, P, P, P, P, P]),
     "gsl_px_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                   P, P, P, P]),
     "gsl_px_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,

@@ -114,9 +114,6 @@ class RenderContext:
         self.slab = 0
         if mode in ("slab4", "slab8"):
             self.slab = int(mode[-1])
-        elif mode == "auto" and os.environ.get("GSLOC_SLAB", "1") != "0":
-            if TINY_RCULL_MAX <= r_max < SLAB_RCULL_MAX:
-                self.slab = 8
         want = (not self.slab and mode in ("auto", "tiny") and os.environ.get("GSLOC_TINY", "1") != "0"
                 and r_max < TINY_RCULL_MAX)
         if want and self.trec is None:

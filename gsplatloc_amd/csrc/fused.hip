@@ -584,6 +584,343 @@ __device__ __forceinline__ void fraster_bwd_body(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compositing backward with the per-splat pixel reduction on the matrix cores.
+// Hardware ablation of k_fraster_bwd (profiles/r02_backward_ablation.txt): its atomics are free, its 64-lane
+// reduce-scatter of 7-10 values per splat is 38 % of the kernel.  Every one of those sums is linear in two per-pixel
+// scalars of the (pixel, splat) pair,
+//     w = vis * v_alpha (0 where alpha is clamped or the pixel did not composite the splat)    f = alpha * T,
+// with per-pixel weights that do not depend on the splat once dx = X - px is expanded around the tile centre:
+//     sum_p w * {1, lx, ly, lx^2, lx ly, ly^2}      (lx, ly = pixel centre - tile centre)
+//     sum_p f * v_colour_k(p)
+// i.e. [splats x pixels] . [pixels x 16] products.  The walk stores w and f of 8 splats as rows of a 16 x 64 tile in
+// LDS (lane = pixel = column: conflict-free stores); 16 v_mfma_f32_16x16x4_f32 (exact f32 fma chains) then produce the
+// 8 x (6 + CG) sums, which are added to the splat's moment row.  At the end of a batch one thread per splat turns its
+// moments into the gradient row  [v_xy | v_conic | v_opacity | v_colour]  (X, Y, conic and opacity are the splat's
+// own), and the rows leave as packed 64-byte global atomics exactly as before.  The matrix pipe runs beside the
+// vector pipe, so the reduction costs the walk ~2 LDS stores per splat.
+// ------------------------------------------------------------------------------------------------
+typedef float gsl_f32x4 __attribute__((ext_vector_type(4)));
+
+#define GSL_MB 192        // list entries staged per batch (three 64-entry chunks)
+#define GSL_MPITCH 72     // floats per tile row: 16-byte reads of lane (k, i) at [i][16 m + 4 k] hit 16 distinct bank quads
+
+template <int D>
+struct FStageM {
+  static constexpr int A = 6 + D;   // moment / gradient row: [6 geometric][D colour]
+  static constexpr int AP = A | 1;  // odd LDS pitch
+  float4 s0[GSL_MB];
+  float4 s1[GSL_MB];
+  float4 s2[(D >= 3) ? GSL_MB : 1];
+  int32_t id[GSL_MB];
+  float acc[GSL_MB * AP];             // per-slot moments, converted in place to the gradient row at flush
+  float tile[4][16 * GSL_MPITCH];     // per wave: rows 0-7 = w of the group's splats, rows 8-15 = f
+  int32_t gslot[4][8];                // batch slot of each splat of the group
+  uint16_t list[4][64];
+};
+
+template <int D, int CG>
+__device__ __forceinline__ void mraster_group_flush(FStageM<D>& sb, int wv, int lane, int count,
+                                                    const float (&bmat)[16]) {
+  // D[i][j] = sum_k A[i][k] B[k][j]; lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; K-step kb
+  // of lane-row k is pixel 16 (kb >> 2) + 4 k + (kb & 3); result row 4 (l >> 4) + r, column l & 15 in register r.
+  constexpr int AP = FStageM<D>::AP;
+  int k = lane >> 4, ij = lane & 15;
+  const float* row = &sb.tile[wv][ij * GSL_MPITCH + 4 * k];
+  gsl_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // rows 0-7 (w) meet the monomial columns, rows 8-15 (f) the colour columns: one B per lane serves both because
+  // the unwanted blocks of the product are simply not read back
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float4 a = *reinterpret_cast<const float4*>(row + 16 * m);
+    float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int kb = 4 * m + u;
+      if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bmat[kb], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bmat[kb], acc0, 0, 0, 0);
+    }
+  }
+  float d[4] = {acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]};
+  // lane rows 0,1 hold the w rows (splat 4 k + r), columns < 6; lane rows 2,3 the f rows (splat 4 (k - 2) + r),
+  // columns 6 .. 6 + CG - 1
+  bool wrow = k < 2;
+  int sbase = 4 * (k & 1);
+  bool col_ok = wrow ? (ij < 6) : (ij >= 6 && ij < 6 + CG);
+  int col = (CG == D || wrow) ? ij : (6 + D - 1);  // depth-only variant: its single colour column is the last one
+  int4 gs = *reinterpret_cast<const int4*>(&sb.gslot[wv][sbase]);
+  int sl[4] = {gs.x, gs.y, gs.z, gs.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (col_ok && sbase + r < count && d[r] != 0.f) atomicAdd(&sb.acc[sl[r] * AP + col], d[r]);
+}
+
+template <int D, int CG>
+__device__ __forceinline__ void mraster_bwd_body(
+    FStageM<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
+    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
+    float px, float py, float qcx, float qcy, float tcx, float tcy, bool inside, int bin_final, int wave_final,
+    float T_final, const float (&vc)[D], float va) {
+  constexpr bool RGB = D >= 3;
+  constexpr bool DEPTH = (D == 1) || (D == 4);
+  constexpr int A = FStageM<D>::A;
+  constexpr int AP = FStageM<D>::AP;
+  int lane = tid & 63, wv = tid >> 6;
+  float T = T_final;
+  float Bp = -T_final * va;
+  unsigned long long insidem = __ballot(inside);
+  // B operand of this lane: K-step kb of lane-row k is pixel (= walk lane) pl = 16 (kb >> 2) + 4 k + (kb & 3)
+  float phi[16], bcol[16];
+  {
+    int k = lane >> 4, j = lane & 15;
+    float wlx = __shfl(px - tcx, 0, 64), wly = __shfl(py - tcy, 0, 64);  // offset of the quadrant's first pixel
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+      int pl = 16 * (kb >> 2) + 4 * k + (kb & 3);
+      float lx = wlx + (float)(pl & 7), ly = wly + (float)(pl >> 3);
+      float m = (j == 0) ? 1.f : (j == 1) ? lx : (j == 2) ? ly : (j == 3) ? lx * lx : (j == 4) ? lx * ly : (j == 5) ? ly * ly : 0.f;
+      phi[kb] = m;
+      bcol[kb] = 0.f;
+    }
+  }
+  if (CG == D) {
+    // colour columns: B[pixel][6 + ch] = upstream gradient of channel ch at that pixel
+    // (exchanged once through this wave's tile, which is not in use yet)
+    float* vcs = sb.tile[wv];
+#pragma unroll
+    for (int ch = 0; ch < D; ++ch) vcs[lane * D + ch] = vc[ch];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int k = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+      int pl = 16 * (kb >> 2) + 4 * k + (kb & 3);
+      if (j >= 6 && j < 6 + D) bcol[kb] = vcs[pl * D + (j - 6)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    int j = lane & 15;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) bcol[kb] = (j == 6) ? 1.f : 0.f;  // f already carries v_depth of its pixel
+  }
+  float bmat[16];  // this lane's column of B: a monomial column (j < 6) or a colour column
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) bmat[kb] = ((lane & 15) < 6) ? phi[kb] : bcol[kb];
+  float* wrow = &sb.tile[wv][lane];
+
+  // The records of batch b + 1 are gathered into registers while batch b is walked (the gather is two dependent
+  // global loads per thread; nothing else in the kernel can cover their latency at 3 workgroups per CU).
+  int pg = 0;
+  float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = pr0, pr2 = pr0;
+  auto gather = [&](int b) {
+    long long bend = re - 1 - (long long)b * GSL_MB;
+    int bsize = (int)min((long long)GSL_MB, bend + 1 - rs);
+    if (tid < bsize) {
+      pg = flatten_ids[bend - tid];
+      pr0 = GSL_Q(Q0, pg);
+      pr1 = GSL_Q(Q1, pg);
+      if (RGB && CG == D) pr2 = GSL_Q(Q2, pg);
+    }
+  };
+  gather(0);
+
+  for (int b = 0; b < nb; ++b) {
+    long long bend = re - 1 - (long long)b * GSL_MB;  // slot t <-> absolute index bend - t (back to front)
+    int bsize = (int)min((long long)GSL_MB, bend + 1 - rs);
+    __syncthreads();
+    if (tid < bsize) {
+      sb.id[tid] = pg;
+      sb.s0[tid] = pr0;
+      sb.s1[tid] = pr1;
+      if (RGB && CG == D) sb.s2[tid] = pr2;
+    }
+    if (tid < GSL_MB) {
+#pragma unroll
+      for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
+    }
+    __syncthreads();
+    if (b + 1 < nb) gather(b + 1);
+    int t_first = (int)max((long long)0, bend - (long long)wave_final);
+    int hh = 0;  // splats in the open group
+    for (int c = (t_first / 64) * 64; c < bsize; c += 64) {
+      int e = c + lane;
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f);
+      if (e < bsize && e >= t_first) {
+        a0 = sb.s0[e];
+        a1 = sb.s1[e];
+      }
+      unsigned long long m = __ballot(fabsf(a0.x - qcx) <= a1.w + 3.5f) & __ballot(fabsf(a0.y - qcy) <= a1.w + 3.5f);
+      if (!m) continue;
+      int t = c + __ffsll((long long)m) - 1;
+      m &= m - 1;
+      float4 q0 = sb.s0[t], q1 = sb.s1[t];
+      for (;;) {
+        // the next survivor's records are requested before this one's arithmetic (wave-uniform LDS addresses)
+        bool more = m != 0;
+        int tn = t;
+        float4 q0n = q0, q1n = q1;
+        if (more) {
+          tn = c + __ffsll((long long)m) - 1;
+          m &= m - 1;
+          q0n = sb.s0[tn];
+          q1n = sb.s1[tn];
+        }
+        float dx = q0.x - px, dy = q0.y - py;
+        float gx = q1.x * dx + q1.y * dy;
+        float gy = q1.y * dx + q1.z * dy;
+        float sigma = 0.5f * (dx * gx + dy * gy);
+        float vis = __expf(-sigma);
+        float opv = q0.w * vis;
+        float alpha = fminf(GSL_ALPHA_MAX, opv);
+        unsigned long long validm = insidem & __ballot((int)(bend - t) <= bin_final) & __ballot(sigma >= 0.f) &
+                                    __ballot(alpha >= GSL_ALPHA_MIN);
+        if (validm) {  // some pixel of this quadrant composited the splat
+          unsigned long long capm = __ballot(opv <= GSL_ALPHA_MAX);
+          float am = sel64(validm, alpha, 0.f);  // other lanes: alpha = 0 => ra = 1, fac = 0, nothing changes
+          float ra = __builtin_amdgcn_rcpf(1.f - am);
+          T *= ra;
+          float fac = am * T;
+          float cdot;
+          if (CG == D) {
+            cdot = 0.f;
+            if (RGB) {
+              float4 q2 = sb.s2[t];
+              cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
+            }
+            if (DEPTH) cdot += q0.z * vc[D - 1];
+          } else {
+            cdot = q0.z * vc[D - 1];
+          }
+          float v_alpha = T * cdot - ra * Bp;
+          Bp += fac * cdot;
+          float vism = sel64(validm & capm, vis, 0.f);  // alpha clamped at 0.999 => no geometric gradient
+          wrow[hh * GSL_MPITCH] = vism * v_alpha;
+          wrow[(8 + hh) * GSL_MPITCH] = (CG == D) ? fac : fac * vc[D - 1];
+          if (lane == 0) sb.gslot[wv][hh] = t;
+          if (++hh == 8) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mraster_group_flush<D, CG>(sb, wv, lane, 8, bmat);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            hh = 0;
+          }
+        }
+        if (!more) break;
+        t = tn;
+        q0 = q0n;
+        q1 = q1n;
+      }
+    }
+    if (hh) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      mraster_group_flush<D, CG>(sb, wv, lane, hh, bmat);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // Moments -> gradient row (one thread per slot), then pack non-zero slots so that 16 consecutive lanes add one
+    // Gaussian's 64-byte row.
+    {
+      bool nz = false;
+      if (tid < bsize) {
+        float mo[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+          mo[k] = sb.acc[tid * AP + k];
+          nz = nz || (mo[k] != 0.f);
+        }
+        if (nz) {
+          float4 q0 = sb.s0[tid], q1 = sb.s1[tid];
+          float X = q0.x - tcx, Y = q0.y - tcy, S = mo[0];
+          float Sx = X * S - mo[1], Sy = Y * S - mo[2];
+          float Sxx = X * (X * S - 2.f * mo[1]) + mo[3];
+          float Sxy = X * (Y * S - mo[2]) - Y * mo[1] + mo[4];
+          float Syy = Y * (Y * S - 2.f * mo[2]) + mo[5];
+          float no = -q0.w;  // v_sigma = -opacity * w
+          sb.acc[tid * AP + 0] = no * (q1.x * Sx + q1.y * Sy);
+          sb.acc[tid * AP + 1] = no * (q1.y * Sx + q1.z * Sy);
+          sb.acc[tid * AP + 2] = 0.5f * no * Sxx;
+          sb.acc[tid * AP + 3] = no * Sxy;
+          sb.acc[tid * AP + 4] = 0.5f * no * Syy;
+          sb.acc[tid * AP + 5] = S;
+        }
+      }
+      unsigned long long mask = __ballot(nz);
+      int cnt = __popcll(mask);
+      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+      __syncthreads();
+      int f = lane & 15;
+      for (int i0 = 0; i0 < cnt; i0 += 4) {
+        int gi = i0 + (lane >> 4);
+        if (gi < cnt && f < A) {
+          int sl = sb.list[wv][gi];
+          size_t g = (size_t)sb.id[sl];
+          atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+        }
+      }
+    }
+  }
+}
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_mraster_bwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+    float* __restrict__ vacc) {
+  __shared__ FStageM<D> sb;
+  __shared__ int s_final[4];
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
+  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W);
+  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;
+  float tcx = (float)(txi * 16) + 8.f, tcy = (float)(tyi * 16) + 8.f;
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs >= re) return;
+
+  size_t pid = inside ? ((size_t)i * W + j) : 0;
+  float Aimg = inside ? alphas[pid] : 0.f;
+  float T_final = 1.f - Aimg;
+  int bin_final = inside ? last_ids[pid] : -1;
+  float vc[D];
+  float va = inside ? v_alphas[pid] : 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
+  if (ED && inside) {
+    float dn = render[pid * D + (D - 1)];
+    float vd = vc[D - 1];
+    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
+    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
+  }
+  int wave_final = bin_final;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
+  if (lane == 0) s_final[wv] = wave_final;
+  bool rgb_grad = false;
+  if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
+  int any_rgb = __syncthreads_or(rgb_grad);
+  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
+  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (rs >= re) return;
+  int nb = (int)((re - rs + GSL_MB - 1) / GSL_MB);
+  if (D == 4 && !any_rgb)
+    mraster_bwd_body<D, 1>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
+                           bin_final, wave_final, T_final, vc, va);
+  else
+    mraster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
+                           bin_final, wave_final, T_final, vc, va);
+}
+
 // Build variant -DGSL_BWD_WAVES=n asks the register allocator for n waves per SIMD (the default build lands at
 // 120 VGPRs = 4 waves; 5 waves = 96 VGPRs costs 13 spilled registers).  Unset in the measured library.
 #ifdef GSL_BWD_WAVES
@@ -937,6 +1274,32 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
   GSL_F_DISPATCH(channels, ed, CALL_FB)
 #undef CALL_FB
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+// Same contract as gsl_fused_raster_bwd; the per-splat pixel sums run on the matrix cores (k_mraster_bwd).
+extern "C" int gsl_mfma_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                                   int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                                   const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                                   const float* render, const float* alphas, const int32_t* last_ids,
+                                   const float* v_render, const float* v_alphas, float* vacc, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0)
+    return GSL_ERR_BAD_ARG;
+  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (capacity == 0 || ty0 == ty1) return GSL_OK;
+  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = (ty1 - ty0) * tile_w;
+#define CALL_MB(DD, EE)                                                                                       \
+  hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
+  GSL_F_DISPATCH(channels, ed, CALL_MB)
+#undef CALL_MB
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

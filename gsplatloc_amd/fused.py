@@ -30,8 +30,11 @@ def _raster_fn(lib, which: str):
     wave-instruction per CU, 45x slower than ds_add_u32), hence the defaults.
     GSLOC_RASTER_FWD / GSLOC_RASTER_BWD override."""
     import os
-    kind = os.environ.get("GSLOC_RASTER_" + which.upper(), "px" if which == "fwd" else "quad")
-    assert kind in ("px", "quad"), kind
+    kind = os.environ.get("GSLOC_RASTER_" + which.upper(), "px" if which == "fwd" else "mfma")
+    assert kind in ("px", "quad", "mfma"), kind
+    if kind == "mfma":  # quad walk, per-splat pixel sums on the matrix cores (backward only)
+        assert which == "bwd"
+        return lib.gsl_mfma_raster_bwd
     return getattr(lib, ("gsl_px_raster_" if kind == "px" else "gsl_fused_raster_") + which)
 
 

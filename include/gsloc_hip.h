@@ -184,6 +184,13 @@ int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int 
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, void* stream);
+/* gsl_fused_raster_bwd with the per-splat pixel sums on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32):
+ * same arguments, same vacc contract. */
+int gsl_mfma_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
+                        int width, int height, int tile_w, int tile_h, int ty0, int ty1,
+                        const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
+                        const float* render, const float* alphas, const int32_t* last_ids,
+                        const float* v_render, const float* v_alphas, float* vacc, void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,

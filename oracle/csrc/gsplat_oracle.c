@@ -36,8 +36,11 @@ static inline real r_ceil(real x) { return sizeof(real) == 4 ? (real)ceilf((floa
 static inline real r_min(real a, real b) { return a < b ? a : b; }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
 
-#define ALPHA_MAX R_(0.999)
-#define ALPHA_MIN (R_(1.0) / R_(255.0))
+/* gsplat's kernels spell these thresholds as float32 literals (0.999f, 1.f / 255.f): the float64 build uses the
+ * float32-representable values, so that a pixel at the clamp takes 1 - alpha = 1 - 0.999f like every float32
+ * implementation does (1 - 0.999 differs from it by 1.3e-5 relative, which would show up as a transmittance error) */
+#define ALPHA_MAX ((GSO_REAL)0.999f)
+#define ALPHA_MIN ((GSO_REAL)(1.0f / 255.0f))
 #define T_STOP R_(1e-4)
 #define RADIUS_LAMBDA_FLOOR R_(0.01)
 #define FOV_LIM R_(1.3)

@@ -27,8 +27,10 @@ import torch
 from torch import Tensor
 
 # ---- named constants of the restated algorithm -------
-ALPHA_MAX = 0.999  # alpha clamp in compositing                      (A.3)
-ALPHA_MIN = 1.0 / 255.0  # contribution cut-off                      (A.3)
+# gsplat spells the two alpha thresholds as float32 literals (0.999f, 1.f / 255.f): the float32-representable values
+# are used at every precision, so that 1 - alpha at the clamp is 1 - 0.999f as in every float32 implementation
+ALPHA_MAX = 0.9990000128746033  # float(np.float32(0.999)): alpha clamp in compositing         (A.3)
+ALPHA_MIN = 0.003921568859368563  # float(np.float32(1) / np.float32(255)): contribution cut-off (A.3)
 T_STOP = 1e-4  # transmittance early-stop threshold (exclusive)      (A.3)
 RADIUS_LAMBDA_FLOOR = 0.01  # max(0.01, b^2-det) under the sqrt       (A.1.6)
 FOV_LIM_FACTOR = 1.3  # symmetric frustum clamp of the EWA Jacobian   (A.1.3)

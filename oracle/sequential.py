@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import numpy as np
 
-ALPHA_MAX, ALPHA_MIN, T_STOP = 0.999, 1.0 / 255.0, 1e-4
+ALPHA_MAX, ALPHA_MIN, T_STOP = 0.9990000128746033, 0.003921568859368563, 1e-4  # float32 literals of gsplat
 
 
 def composite_fwd(means2d, conics, colors, opac, W, H, tile, offsets, flat_ids, dtype=np.float64):

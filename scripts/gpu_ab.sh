@@ -21,12 +21,12 @@ run_tests() {
   timeout -k 10 "$to" python -m pytest "$@" -m gpu -q > "gpurun_out/${log}.log" 2>&1
   local rc=$?; tail -6 "gpurun_out/${log}.log"; guard $rc
 }
-run_tests t_small 600 tests/test_gpu_parity.py -k "small_splat or outgrew"
-run_bench s1_slab8
-GSLOC_BWD=general run_bench s1_general
-run_bench s0r_tiny --sigma-px 0 --order raster
-GSLOC_BWD=slab4 run_bench s0r_slab4 --sigma-px 0 --order raster
-GSLOC_BWD=slab8 run_bench s0r_slab8 --sigma-px 0 --order raster
-run_bench s1r_slab8 --order raster
+run_tests t_mfma 600 tests/test_gpu_parity.py -k "fused_full or end_to_end or tile_strip or small_splat"
+run_bench s1_mfma
+GSLOC_RASTER_BWD=quad run_bench s1_quad
+GSLOC_BWD=general run_bench s0r_mfma --sigma-px 0 --order raster
+GSLOC_BWD=general GSLOC_RASTER_BWD=quad run_bench s0r_quad --sigma-px 0 --order raster
+run_bench s1_mfma_poseonly --pose-only
 run_tests t_parity 900 tests/test_gpu_parity.py
 run_tests t_configs 900 tests/test_gpu_configs.py
+run_tests t_rest 900 tests --ignore=tests/test_gpu_parity.py --ignore=tests/test_gpu_configs.py
