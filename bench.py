@@ -5,15 +5,19 @@ One "step" = one full pass of the path BASELINE.json names on a batch of synthet
 projection + SH colour -> tile binning + per-tile depth sort -> alpha compositing ("RGB+ED",
 the reference's call, /root/reference/src/my_gsplat/model.py:195-213) -> backward from a given
 depth-channel gradient to every Gaussian input and to the 4x4 view matrix.  Inputs are resident
-in HBM before the timed region.  Workload "R" of SURVEY.md 8(d): N = 1,000,000 Gaussians,
-1200x680, sigma_px = 1.0 (I/N ~ 2.4 tile intersections per Gaussian).
+in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload R|S|T|X]
+
+Workloads (SURVEY.md 8d / BASELINE.json configs): R (default, the metric's configuration) = 1 M random Gaussians,
+1200x680, sigma_px = 1; X = 5 M random Gaussians, 1920x1080; S = a 640x480 depth frame back-projected to 102 400
+Gaussians with the reference's as-coded kNN scales; T = one Gaussian per pixel of a 640x480 depth frame with
+invalid (zero) depths, 307 200 Gaussians.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): screen-tile rows are
-split across ranks, every rank renders and back-propagates its strip for all N Gaussians, and
-the 12+4 pose-gradient floats are summed with ONE all-reduce per step (strong scaling: the
-frame is fixed, value = Gaussians of the frame / step time).
+split across ranks, every rank renders and back-propagates its strip, and the 12+4 pose-gradient floats are
+summed with ONE all-reduce per step (strong scaling: the frame is fixed, value = Gaussians of the frame / step
+time).  Each rank replays one HIP graph per step (library launches only) and then issues the collective.
 """
 from __future__ import annotations
 
@@ -29,20 +33,29 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+WORKLOADS = {
+    "R": dict(n=1_000_000, width=1200, height=680, sigma_px=1.0, order="random", kind="random"),
+    "X": dict(n=5_000_000, width=1920, height=1080, sigma_px=1.0, order="random", kind="random"),
+    "S": dict(n=102_400, width=640, height=480, kind="depth_frame", stride=3, holes=False),
+    "T": dict(n=307_200, width=640, height=480, kind="depth_frame", stride=1, holes=True),
+}
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_traffic.json")
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=1_000_000,
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="R")
+    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=None,
                     help="(--n is an ambiguous prefix for torch.distributed.run's own parser: use --gaussians there)")
-    ap.add_argument("--width", type=int, default=1200)
-    ap.add_argument("--height", type=int, default=680)
-    ap.add_argument("--sigma-px", type=float, default=1.0)
-    ap.add_argument("--order", choices=["random", "raster"], default="random")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--sigma-px", type=float, default=None)
+    ap.add_argument("--order", choices=["random", "raster"], default=None)
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity block")
     ap.add_argument("--cpu-sample-div", type=int, default=3,
                     help="fallback cpu_baseline (torch oracle) sample: N/div^2 Gaussians on a (W/div)x(H/div) image")
     ap.add_argument("--no-tracker", action="store_true", help="skip the pose-opt iterations/s side measurement")
@@ -50,7 +63,15 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank path with every rank on cuda:0 and a gloo (host) all-reduce")
-    return ap.parse_args()
+    args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    explicit = any(getattr(args, k) is not None for k in ("n", "width", "height", "sigma_px", "order"))
+    for key in ("n", "width", "height", "sigma_px", "order"):
+        if getattr(args, key) is None:
+            setattr(args, key, wl.get(key, {"sigma_px": 0.0, "order": "raster"}.get(key)))
+    # explicit sizes always mean the random-N scene; the depth-frame workloads are selected by name only
+    args.kind = "random" if (explicit or wl["kind"] == "random") else "depth_frame"
+    return args
 
 
 def trace(msg):
@@ -61,7 +82,7 @@ def trace(msg):
 
 
 def algorithmic_bytes(N, I, P, D, n_tiles, full):
-    """BASELINE.md section 3 byte model, per stage (bytes per step)."""
+    """SURVEY.md 8(d) / BASELINE.md section 3 byte model, per stage (bytes per step)."""
     import math
     p = math.ceil((32 + math.ceil(math.log2(max(n_tiles, 2)))) / 8)
     g = 1 if full else 0
@@ -74,18 +95,25 @@ def algorithmic_bytes(N, I, P, D, n_tiles, full):
     }
 
 
+def implementation_bin_bytes(N, I, n_tiles):
+    """What THIS build's binning moves (no credit for radix passes it does not run): the scatter reads a 16-byte
+    record and a radius per Gaussian and writes one 8-byte key per intersection; the per-tile sort reads the keys
+    and writes the 4-byte Gaussian ids; counts, offsets and cursors are 12 bytes per tile."""
+    return N * 20 + I * (8 + 8 + 4) + n_tiles * 12
+
+
 STAGE_KERNELS = {  # stage timer -> kernels it brackets (names as rocprofv3 prints them, template arguments dropped)
     "project_fwd": ("k_fproject<",), "bin": ("k_ftile_scan", "k_fscatter", "k_tile_sort"),
-    "raster_fwd": ("k_praster_fwd", "k_fraster_fwd"), "raster_bwd": ("k_mraster_bwd", "k_fraster_bwd", "k_praster_bwd", "k_sraster_bwd", "k_tiny_bwd", "k_tiny_gather"),
+    "raster_fwd": ("k_praster_fwd",), "raster_bwd": ("k_mraster_bwd", "k_tiny_bwd", "k_tiny_gather"),
     "project_bwd": ("k_fproject_bwd", "k_freduce_viewmat"),
 }
 
 
 def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernels from the committed PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, made by scripts/pmc_summary.py from separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs; counters cannot be read from inside the process).  None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of the stage's kernels from the committed PMC passes of this same command (made by
+    scripts/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; counters cannot be read from inside
+    the process).  None when the file is absent."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
@@ -93,32 +121,40 @@ def pmc_traffic(stage):
     return sum(tot) if tot else None
 
 
-def cpu_baseline(args):
-    """The CPU oracle (the 'port') timed on the host cores: oracle/csrc/gsplat_oracle.c built for float32 (the
-    arithmetic type of the HIP path) with OpenMP on min(host cores, 16) threads -- a 1-GPU box exposes a 16-core
-    share -- on the FULL workload (same N, image, sigma_px, order, gradient outputs), one warm-up step and the best
-    of two timed steps (~10 s of CPU work).  If the C library cannot be built, the PyTorch oracle on a
-    same-density subsample (N/div^2 on W/div x H/div) is timed instead and says so."""
+def build_scene(args, dev):
+    """The synthetic input of the workload (seeded) and the camera it is rendered from."""
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
 
-    cores = min(os.cpu_count() or 1, 16)
-    V = torch.linalg.inv(perturbed_pose())
+    if args.kind == "depth_frame":
+        from gsplatloc_amd.synthetic import depth_frame_scene
+        wl = WORKLOADS[args.workload]
+        return depth_frame_scene(args.width, args.height, stride=wl["stride"], holes=wl["holes"], device=dev)
+    sc = random_scene(args.n, args.width, args.height, sigma_px=args.sigma_px, device=dev, order=args.order)
+    sc["viewmat"] = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    return sc
+
+
+def cpu_baseline(args, scene, gpu):
+    """The CPU oracle (the 'port') timed on the host cores: oracle/csrc/gsplat_oracle.c built for float32 (the
+    arithmetic type of the HIP path) with OpenMP on every host core, on the FULL workload (same inputs, same
+    gradient outputs), one warm-up step and the best of two timed steps.  The same leg checks the GPU result against
+    the oracle's float64 build (the `parity` object): images on all pixels, the pose gradient flip-aware (upstream
+    gradient zeroed where the two renders disagree beyond the image tolerance).  If the C library cannot be built,
+    the PyTorch oracle on a same-density subsample is timed instead and says so."""
+    cores = os.cpu_count() or 1
+    V = scene["viewmat"].cpu()
     try:
         from oracle import c_oracle
         c_oracle.load("f32")
     except Exception as exc:  # no compiler on the box and no prebuilt library: fall back to the torch oracle
-        return cpu_baseline_torch(args, cores, V, reason=f"{type(exc).__name__}: {exc}")
-    n, w, h = args.n, args.width, args.height
-    sc = random_scene(n, w, h, sigma_px=args.sigma_px, order=args.order)
-    g = torch.Generator().manual_seed(1)
-    v = torch.zeros(h, w, 4)
-    v[..., 3] = torch.randn(h, w, generator=g)
-    arrays = [sc[k].numpy() for k in ("means", "quats", "scales", "opacities", "sh")] + [V.numpy(), sc["K"].numpy()]
-    v = v.numpy()
+        return cpu_baseline_torch(args, cores, V, reason=f"{type(exc).__name__}: {exc}"), None
+    n, w, h = scene["means"].shape[0], args.width, args.height
+    arrays = [scene[k].cpu().numpy() for k in ("means", "quats", "scales", "opacities", "sh")] + [V.numpy(), scene["K"].cpu().numpy()]
+    v = gpu["v_render"].cpu().numpy()
 
-    def step():
-        return c_oracle.rasterization(*arrays, w, h, sh_degree=1, render_mode="RGB+ED", v_render=v, precision="f32",
-                                      threads=cores)
+    def step(precision="f32", v_render=v):
+        return c_oracle.rasterization(*arrays, w, h, sh_degree=1, render_mode="RGB+ED", v_render=v_render,
+                                      precision=precision, threads=cores)
 
     step()
     ts = []
@@ -127,10 +163,31 @@ def cpu_baseline(args):
         out = step()
         ts.append(time.perf_counter() - t)
     dt = min(ts)
-    return {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/csrc/gsplat_oracle.c float32 + OpenMP, the full workload (N={n}, {w}x{h}, "
-                      f"{out['n_isects']} intersections), fwd+bwd with all gradients, best of 2 after one warm-up "
-                      f"step, {dt:.2f} s/step"}
+    base = {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/csrc/gsplat_oracle.c float32 + OpenMP on {cores} threads, the full workload (N={n}, "
+                      f"{w}x{h}, {out['n_isects']} intersections), fwd+bwd with all gradients, best of 2 after one "
+                      f"warm-up step, {dt:.2f} s/step"}
+    parity = None
+    if gpu.get("render") is not None:
+        import numpy as np
+        ref = step("f64", None)
+        rg, ag = gpu["render"].cpu().double().numpy(), gpu["alphas"].cpu().double().numpy()[..., 0]
+        d_rel = np.abs(rg[..., 3] - ref["render"][..., 3]) / np.maximum(np.abs(ref["render"][..., 3]), 1e-3)
+        ok = (np.abs(rg - ref["render"]) <= 2e-5 + 1e-4 * np.abs(ref["render"])).all(-1) & (
+            np.abs(ag - ref["alphas"]) <= 2e-5 + 1e-4 * np.abs(ref["alphas"]))
+        vm = v * ok[..., None]
+        want = step("f64", vm)
+        got = gpu["backward"](torch.from_numpy(vm))
+        gv, wv = got.cpu().double().numpy()[:3], want["v_viewmat"][:3]
+        parity = {"against": "oracle/csrc/gsplat_oracle.c float64", "tolerance": "1e-4 relative (north_star)",
+                  "depth_rel_err": {"mean": float(d_rel.mean()), "p99": float(np.quantile(d_rel.reshape(-1)[::7], 0.99)),
+                                    "max_over_agreeing_pixels": float(d_rel[ok].max())},
+                  "alpha_abs_err": {"mean": float(np.abs(ag - ref["alphas"]).mean()),
+                                    "max_over_agreeing_pixels": float(np.abs(ag - ref["alphas"])[ok].max())},
+                  "pixels_beyond_tolerance": float(1.0 - ok.mean()),
+                  "v_viewmat_rel_err": float(np.abs(gv - wv).max() / np.abs(wv).max()),
+                  "n_isects": [int(gpu["n_isects"]), int(ref["n_isects"])]}
+    return base, parity
 
 
 def cpu_baseline_torch(args, cores, V, reason):
@@ -161,6 +218,19 @@ def cpu_baseline_torch(args, cores, V, reason):
             "sample": f"oracle/gsplat_oracle.py fp32 (C oracle unavailable: {reason}), N={n} on {w}x{h} "
                       f"(N/{div * div}, W/{div} x H/{div} of the workload, same splat density), fwd+bwd, best of 2 "
                       f"after one warm-up step, {dt:.2f} s/step"}
+
+
+def backward_name(ctx):
+    return "tiny-splat slabs + 4-lane gather" if getattr(ctx, "tiny", False) else "quadrant walk + MFMA pixel sums"
+
+
+def event_stats(ms):
+    """median / p10 / p90 of the per-step durations measured with HIP events on the launch stream."""
+    if not ms:
+        return None
+    s = sorted(ms)
+    q = lambda f: s[min(len(s) - 1, int(round(f * (len(s) - 1))))]  # noqa: E731
+    return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": len(s)}
 
 
 def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
@@ -203,14 +273,6 @@ def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
     ctx.check_capacity()
     return {"sigma_px": sigma_px, "order": order, "intersections_per_gaussian": n_is / N, "ms_per_step": dt * 1e3,
             "gaussians_per_s": N / dt, "backward": backward_name(ctx)}
-
-
-def backward_name(ctx):
-    if getattr(ctx, "slab", 0):
-        return f"per-pixel walk + {ctx.slab}x{ctx.slab} LDS slabs"
-    import os
-    kind = os.environ.get("GSLOC_RASTER_BWD", "mfma")
-    return "tiny-splat slabs (global)" if getattr(ctx, "tiny", False) else {"mfma": "quadrant walk + MFMA pixel sums", "quad": "quadrant walk + wave reduce-scatter", "px": "per-pixel two-phase"}[kind]
 
 
 def pose_opt_rate(dev):
@@ -276,16 +338,16 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
-    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd import context as C
     from gsplatloc_amd.parallel import strip_rows
-    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
 
-    N, W, H = args.n, args.width, args.height
-    sc = random_scene(N, W, H, sigma_px=args.sigma_px, device=dev, order=args.order)
-    viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
-    K = sc["K"].contiguous()
+    scene = build_scene(args, dev)
+    N, W, H = scene["means"].shape[0], args.width, args.height
+    viewmat = scene["viewmat"]
+    K = scene["K"].contiguous()
     th = (H + 15) // 16
     full = not args.pose_only
+    sc = {k: scene[k] for k in ("means", "quats", "scales", "opacities", "sh")}
 
     # ---- tile-row strip of this rank (balanced on a calibration pass) -------------------------
     rows = (0, th)
@@ -294,16 +356,16 @@ def main():
         # once per frame (untimed): balance strips on a full binning pass, keep the Gaussians that can reach
         # this rank's strip (1-tile guard band), the rest never touch its pixels
         from gsplatloc_amd.parallel import gaussians_for_strip
-        cal = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
+        cal = C.RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
         cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
         rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank]
         idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
-        for k in ("means", "quats", "scales", "opacities", "sh"):
+        for k in sc:
             sc[k] = sc[k][idx].contiguous()
         n_local = int(idx.numel())
         del cal
         trace(f"strip rows {rows}, {n_local} local Gaussians")
-    ctx = RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full)
+    ctx = C.RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full)
     n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
     trace(f"calibrated, {n_isects} intersections")
     g = torch.Generator().manual_seed(1)
@@ -311,37 +373,56 @@ def main():
     v_render[..., 3] = torch.randn(H, W, generator=g)
     v_render = v_render.to(dev)
     v_alphas = torch.zeros(H, W, 1, device=dev)
-    pose_grad = torch.zeros(16, device=dev)
+    pose_grad = torch.zeros(16, device=dev)  # this rank's 16 floats of the all-reduce
+    host16 = None
+    if dist is not None and args.rehearse_on_one_gpu:
+        host16 = torch.zeros(16).pin_memory()
     args_in = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
 
-    def step():
+    def render_step():
+        """The rank's launches of one step: library kernels and memsets only (captured as one HIP graph)."""
         ctx.forward(*args_in)
         grads = ctx.backward(v_render, v_alphas, full=full)
-        if dist is not None:
-            if args.rehearse_on_one_gpu:
-                host = grads["viewmat"].reshape(16).cpu()
-                dist.all_reduce(host)
-                pose_grad.copy_(host)
-            else:
+        if dist is not None:  # pack the 12 pose-gradient entries (+4 spare) into the all-reduce buffer
+            if os.environ.get("GSLOC_DIAG_CAPTURED_COPY"):  # diagnosis of round 1's fault: a torch copy node in the graph
                 pose_grad.copy_(grads["viewmat"].reshape(16))
-                dist.all_reduce(pose_grad)  # THE collective of the path: 12 pose-gradient entries (+4 spare)
+            else:
+                C.pack_pose_reduce(grads["viewmat"], pose_grad)
+
+    def collective():
+        """THE collective of the path: one all-reduce of 16 floats (RCCL on the device buffer; the one-GPU
+        rehearsal's gloo group goes through a pinned host buffer)."""
+        if host16 is not None and os.environ.get("GSLOC_DIAG_PAGEABLE"):  # diagnosis: round 1's pageable host path
+            host = pose_grad.cpu()
+            dist.all_reduce(host)
+            pose_grad.copy_(host)
+        elif host16 is not None:
+            host16.copy_(pose_grad, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            dist.all_reduce(host16)
+            pose_grad.copy_(host16, non_blocking=True)
+        else:
+            dist.all_reduce(pose_grad)
 
     graph = None
     side = torch.cuda.Stream()
-    if not args.no_graph and dist is None:
-        # one iteration = a fixed sequence of 10 launches: replay it as a single HIP graph.  (N > 1 launches
-        # eagerly: a per-rank graph followed by the collective faulted in the one-GPU rehearsal)
+    if not args.no_graph:
         with torch.cuda.stream(side):
             for _ in range(2):
-                step()
+                render_step()
             torch.cuda.synchronize()
             trace("eager steps done")
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                step()
+                render_step()
         torch.cuda.synchronize()
         trace("graph captured")
-    run = graph.replay if graph is not None else step
+    render = graph.replay if graph is not None else render_step
+
+    def run():
+        render()
+        if dist is not None:
+            collective()
 
     for _ in range(args.warmup):
         run()
@@ -350,9 +431,12 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for e0, e1 in events:
+        e0.record()
         run()
+        e1.record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -364,40 +448,48 @@ def main():
         dt = float(t.item())
     n_total = ctx.check_capacity()
     ms = dt / args.steps * 1e3
+    step_ms = guarded(lambda: event_stats([a.elapsed_time(b) for a, b in events]))
     trace("timed steps done")
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps, second pass -------
     stage_ms = {}
     if rank == 0:
-        from gsplatloc_amd import context as C
         stage_ms = guarded(C.time_stages, ctx, args_in, v_render, v_alphas, full, steps=min(args.steps, 20))
         if "error" in stage_ms:
             stage_ms = {}
 
     if rank == 0:
         P = W * H
-        bytes_stage = algorithmic_bytes(n_local, n_total, P if world == 1 else (rows[1] - rows[0]) * 16 * W, 4,
-                                        ctx.n_tiles, full)
+        P_local = P if world == 1 else (min(rows[1] * 16, H) - rows[0] * 16) * W
+        bytes_stage = algorithmic_bytes(n_local, n_total, P_local, 4, ctx.n_tiles, full)
+        impl_bytes = dict(bytes_stage, bin=implementation_bin_bytes(n_local, n_total, ctx.n_tiles))
         dom = max(stage_ms, key=stage_ms.get) if stage_ms else "raster_bwd"
         dom_ms = stage_ms.get(dom)  # None if the stage timing pass failed
         achieved = bytes_stage[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms else None
+        headline = args.workload == "R" and args.kind == "random" and args.sigma_px == 1.0 and args.order == "random"
+        if args.kind == "random":
+            what = f"{args.workload}: {N} random Gaussians ({args.order} order), {W}x{H}, sigma_px={args.sigma_px}"
+        else:
+            what = (f"{args.workload}: {N} Gaussians back-projected from a {W}x{H} depth frame (raster order, as-coded "
+                    f"kNN scales{', invalid depths' if WORKLOADS[args.workload]['holes'] else ''})")
         out = {
-            "metric": "Gaussians/s fwd+bwd @1M splats 1200x680",
+            "metric": "Gaussians/s fwd+bwd @1M splats 1200x680" if (headline and N == 1_000_000) else
+                      f"Gaussians/s fwd+bwd @{N} splats {W}x{H} (workload {args.workload})",
             "value": N / (dt / args.steps),
             "unit": "Gaussians/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,
+            "step_ms_hip_events": step_ms,
             "higher_is_better": True,
             "scaling": "strong",  # the frame (N Gaussians, one image) is fixed; more GPUs split its tile rows
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"R: {N} random Gaussians ({args.order} order), {W}x{H}, sigma_px={args.sigma_px}, "
-                            f"render_mode=RGB+ED sh_degree=1, backward from a depth-channel gradient, "
-                            f"{'full per-Gaussian gradients + pose gradient' if full else 'pose gradient only'}",
+                "workload": what + ", render_mode=RGB+ED sh_degree=1, backward from a depth-channel gradient, "
+                            + ("full per-Gaussian gradients + pose gradient" if full else "pose gradient only"),
                 "intersections_per_gaussian": (n_total / N) if world == 1 else None,
                 "strip_intersections_rank0": n_total, "tile_rows_rank0": list(rows), "gaussians_rank0": n_local,
                 "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
@@ -407,16 +499,40 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": (achieved / 8000.0) if achieved else None,
-                "traffic": pmc_traffic(dom) if (world == 1 and args.sigma_px == 1.0 and args.order == "random" and N == 1_000_000) else None,
+                "traffic": pmc_traffic(dom) if (world == 1 and headline and N == 1_000_000) else None,
+                "traffic_source": f"committed rocprofv3 --pmc summary {PMC_SUMMARY} of this command (not measured in this run)",
                 "algorithmic_bytes_per_launch": bytes_stage[dom], "avg_launch_ms": dom_ms,
-                "whole_step": {"algorithmic_bytes": sum(bytes_stage.values()),
+                "whole_step": {"model": "SURVEY.md 8(d)", "algorithmic_bytes": sum(bytes_stage.values()),
                                "achieved_GBps": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9,
                                "frac": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9 / 8000.0},
+                "whole_step_implementation_bytes": {
+                    "note": "bin stage counted as what this build moves (keys written once, sorted in LDS, ids written)",
+                    "algorithmic_bytes": sum(impl_bytes.values()),
+                    "frac": sum(impl_bytes.values()) / (ms * 1e-3) / 1e9 / 8000.0},
                 "stage_ms": stage_ms,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = guarded(cpu_baseline, args)
+            def gpu_backward(vm):
+                ctx.forward(*args_in)
+                grads = ctx.backward(vm.float().to(dev).contiguous(), v_alphas, full=full)
+                torch.cuda.synchronize()
+                return grads["viewmat"].clone()
+
+            def baseline_and_parity():
+                ctx.forward(*args_in)
+                torch.cuda.synchronize()
+                gpu = {"render": getattr(ctx, "render", None), "alphas": getattr(ctx, "alphas", None),
+                       "v_render": v_render, "backward": gpu_backward, "n_isects": n_total}
+                if gpu["render"] is not None:
+                    gpu["render"], gpu["alphas"] = gpu["render"].clone(), gpu["alphas"].clone()
+                return cpu_baseline(args, dict(scene, K=K), gpu)
+
+            res = guarded(baseline_and_parity)
+            if isinstance(res, tuple):
+                out["cpu_baseline"], out["parity"] = res
+            else:
+                out["cpu_baseline"] = res
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_tracker:
@@ -424,7 +540,7 @@ def main():
         if world == 1 and not args.no_variants:
             # same N and image, the other synthetic inputs of SURVEY.md 8(d): sigma_px -> 0 is the regime of the
             # reference's as-coded kNN scales; "raster" is the Gaussian order of a back-projected depth frame
-            out["variants"] = [guarded(variant_rate, dev, N, W, H, s_, o_) for s_, o_ in
+            out["variants"] = [guarded(variant_rate, dev, args.n, W, H, s_, o_) for s_, o_ in
                                ((1.0, "raster"), (0.0, "random"), (0.0, "raster"))]
         print(json.dumps(out))
     if dist is not None:

@@ -14,12 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# Build variants (csrc/Makefile: aos = interleaved 64-byte records, occ5 = backward at 5 waves/SIMD, xcd = one tile span
-# per XCD) are loaded only
-# on request -- GSLOC_LIB_VARIANT=<name>, or GSLOC_AOS=1 for "aos"; default: the measured library
-_VARIANT = os.environ.get("GSLOC_LIB_VARIANT", "aos" if os.environ.get("GSLOC_AOS") == "1" else "")
-_VARIANT = f"_{_VARIANT}" if _VARIANT else ""
-_LIB_PATH = os.path.join(_HERE, f"libgsloc_hip{_VARIANT}.so")
+_LIB_PATH = os.path.join(_HERE, "libgsloc_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
 P = c_void_p  # every device pointer travels as void*
@@ -27,7 +22,6 @@ P = c_void_p  # every device pointer travels as void*
 _SIGNATURES = {
     "gsl_version": (c_char_p, []),
     "gsl_status_string": (c_char_p, [c_int]),
-    "gsl_record_stride": (c_int, []),
     "gsl_project_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
                                 P, P, P, P, P, P]),
     "gsl_project_bwd_ws_bytes": (c_size_t, [c_int]),
@@ -46,21 +40,16 @@ _SIGNATURES = {
                                   P]),
     "gsl_fused_bin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P, P, P, P, c_size_t, P]),
     "gsl_fused_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, P]),
+                                     P, P, P, c_int, c_int, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, P, P, P, P]),
-    "gsl_mfma_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                    P, P, P, P, P, P, P]),
-    "gsl_px_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                  P, P, P, P]),
-    "gsl_px_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                  P, P, P, P, P, P, P]),
+                                     P, P, P, P, P, P, c_int, c_int, P]),
     "gsl_loss_ws_bytes": (c_size_t, [c_int, c_int]),
     "gsl_tracking_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_size_t,
                                   P]),
     "gsl_pose_init": (c_int, [P, P, P, c_float, c_float, P, P, P]),
     "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                               c_float, c_float, c_float, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "gsl_pack_pose_reduce": (c_int, [P, P, c_int, P, P]),
     "gsl_knn_ws_bytes": (c_size_t, [c_int]),
     "gsl_knn_cells": (c_int, []),
     "gsl_knn_count": (c_int, [P, c_int, P, P, c_size_t, P]),
@@ -68,14 +57,8 @@ _SIGNATURES = {
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_tiny_gather": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
-    "gsl_tiny_gather4": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
-    "gsl_tiny_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
-                                     P, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                    P, P, P, P, P, P, P, P]),
-    "gsl_slab_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                    P, P, P, P, P, P, P, P]),
-    "gsl_debug_reduce_scatter": (c_int, [P, P, P]),
+                                    P, P, P, P, P, P, P, c_int, c_int, P, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "gsl_isect_offsets": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),
     "gsl_rasterize_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P,
@@ -99,7 +82,7 @@ def exported_symbols():
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libgsloc_hip.so (in-tree)."""
     csrc = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "all", "variants"]
+    cmd = ["make", "-C", csrc, "-j", str(min(8, os.cpu_count() or 1)), "all"]
     if force:
         subprocess.run(["make", "-C", csrc, "clean"], check=True, capture_output=not verbose)
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -19,18 +19,18 @@ import torch
 from torch import Tensor
 
 from ._lib import check, current_stream, load_library, ptr
-from .fused import _MODES, MAX_STRIP_TILES, _raster_fn, alloc_records, tile_n_bits
+from .fused import _MODES, MAX_STRIP_TILES, alloc_records, tile_n_bits
 
 
 TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
-SLAB_RCULL_MAX = 3.999  # ... at most 8 pixel centres per axis (sigma_px <= ~1.1 at opacity 1)
 
 
 class RenderContext:
     def __init__(self, N: int, width: int, height: int, render_mode: str = "RGB+ED", sh_degree: Optional[int] = 1,
                  K_sh: int = 4, device="cuda", eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10,
                  radius_clip: float = 0.0, antialiased: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
-                 capacity: Optional[int] = None, full_grads: bool = True):
+                 capacity: Optional[int] = None, full_grads: bool = True,
+                 pixel_rows: Optional[Tuple[int, int]] = None):
         self.lib = load_library()
         self.N, self.W, self.H = int(N), int(width), int(height)
         self.mode = render_mode
@@ -45,6 +45,10 @@ class RenderContext:
         self.ty0, self.ty1 = tile_rows if tile_rows is not None else (0, self.th)
         assert 0 <= self.ty0 <= self.ty1 <= self.th
         assert (self.ty1 - self.ty0) * self.tw <= MAX_STRIP_TILES, "strip too large for the LDS tile histogram"
+        # pixel rows actually composited inside the tile rows (a strip plus its one-pixel Sobel halo); default: all
+        lo, hi = self.ty0 * 16, min(self.ty1 * 16, self.H)
+        self.row0, self.row1 = pixel_rows if pixel_rows is not None else (lo, hi)
+        assert lo <= self.row0 <= self.row1 <= hi or self.ty0 == self.ty1, (pixel_rows, tile_rows)
         self.full_grads = bool(full_grads)
         dev = torch.device(device)
         self.device = dev
@@ -76,14 +80,7 @@ class RenderContext:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
         self.capacity = 0
         self.tiny = False
-        self.slab = 0  # box of the slab backward (4 or 8) when every splat is small enough, else 0
-        self.flags = torch.zeros(4, dtype=i32, device=dev)  # [0] slab miss (sticky, set by the kernels)
-        # pass 2 of the tiny-splat backward: the measured kernel unless the untested 4-lane variant is asked for
-        import os
-        self._tiny_gather = (self.lib.gsl_tiny_gather4 if os.environ.get("GSLOC_TINY_GATHER") == "4"
-                             else self.lib.gsl_tiny_gather)
-        # untested variant: the gather runs inside the projection backward (one kernel, rows stay in LDS)
-        self._tiny_fused = os.environ.get("GSLOC_TINY_FUSED") == "1"
+        self.flags = torch.zeros(4, dtype=i32, device=dev)  # [0] a splat outgrew the tiny backward (sticky, device-set)
         self.trec = self.vcT = None
         self.keys = self.flatten_ids = None
         if capacity is not None:
@@ -107,19 +104,25 @@ class RenderContext:
     def _choose_backward(self) -> None:
         """Tiny-splat backward (per-splat 4x4 record slabs, no reduction, no atomics) when no splat reaches
         more than 4x4 pixel centres (r_cull < 2 px) -- GsplatLoc's as-coded scales; otherwise the general
-        compositing backward.  GSLOC_TINY=0 disables."""
+        compositing backward.  GSLOC_BWD=general disables it (dev switch)."""
         import os
         r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
-        mode = os.environ.get("GSLOC_BWD", "auto")  # auto | general | tiny | slab4 | slab8 (dev switch)
-        self.slab = 0
-        if mode in ("slab4", "slab8"):
-            self.slab = int(mode[-1])
-        want = (not self.slab and mode in ("auto", "tiny") and os.environ.get("GSLOC_TINY", "1") != "0"
-                and r_max < TINY_RCULL_MAX)
+        want = os.environ.get("GSLOC_BWD", "auto") != "general" and r_max < TINY_RCULL_MAX
         if want and self.trec is None:
             self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
             self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
         self.tiny = want
+        self.flags.zero_()
+
+    def tiny_overflowed(self) -> bool:
+        """Host sync: did a splat outgrow the tiny backward since the last calibration?  (The kernel raises the
+        sticky device flag instead of dropping the gradient silently.)"""
+        return bool(self.tiny and int(self.flags[0].item()))
+
+    def use_general_backward(self) -> None:
+        """Recovery after tiny_overflowed(): switch this context to the general compositing backward."""
+        self.tiny = False
+        self.flags.zero_()
 
     def check_capacity(self) -> int:
         """Host sync: intersections of the last forward; raises if they did not fit (or if a splat outgrew the
@@ -127,10 +130,8 @@ class RenderContext:
         n = int(self.n_is.item())
         if n > self.capacity:
             raise RuntimeError(f"intersection capacity exceeded ({n} > {self.capacity}); call calibrate() again")
-        if self.tiny and float(self.Q1[:, 3].max()) >= TINY_RCULL_MAX:
+        if self.tiny_overflowed():
             raise RuntimeError("a splat outgrew the tiny-splat backward (r_cull >= 2 px); call calibrate() again")
-        if self.slab and int(self.flags[0].item()):
-            raise RuntimeError(f"a splat outgrew the {self.slab}x{self.slab} slab backward; call calibrate() again")
         return n
 
     # ------------------------------------------------------------------ stages (one C-ABI call each)
@@ -149,40 +150,28 @@ class RenderContext:
               "gsl_fused_bin")
 
     def _raster_fwd(self) -> None:
-        check(_raster_fn(self.lib, 'fwd')(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
-                                          self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
-                                          ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
-                                          ptr(self.last_ids), current_stream()), "raster_fwd")
+        check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
+                                            self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
+                                            ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
+                                            ptr(self.last_ids), self.row0, self.row1, current_stream()),
+              "gsl_fused_raster_fwd")
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,
                   self.ty0, self.ty1, ptr(self.offs), ptr(self.flatten_ids), self.capacity, ptr(self.render),
                   ptr(self.alphas), ptr(self.last_ids), ptr(v_render), ptr(v_alphas))
-        if self.slab:
-            check(self.lib.gsl_slab_raster_bwd(*common[:5], self.slab, *common[5:], ptr(self.vacc), ptr(self.flags),
-                                               current_stream()), "gsl_slab_raster_bwd")
-        elif self.tiny:
-            check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), current_stream()),
-                  "gsl_tiny_raster_bwd")
-            if not self._tiny_fused:
-                check(self._tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W, self.H,
-                                        ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
-                      "gsl_tiny_gather")
+        if self.tiny:
+            check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), self.row0, self.row1,
+                                               ptr(self.flags), current_stream()), "gsl_tiny_raster_bwd")
+            check(self.lib.gsl_tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W, self.H,
+                                           ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
+                  "gsl_tiny_gather")
         else:
-            check(_raster_fn(self.lib, 'bwd')(*common, ptr(self.vacc), current_stream()), "raster_bwd")
+            check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, current_stream()),
+                  "gsl_fused_raster_bwd")
 
     def _project_bwd(self, full: bool) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
-        if self.tiny and self._tiny_fused:
-            check(self.lib.gsl_tiny_project_bwd(
-                ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
-                self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
-                ptr(self.radii), ptr(self.Q0), ptr(self.Q1), ptr(self.comps), ptr(self.trec), ptr(self.vcT),
-                ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
-                ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
-                ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
-                self.n_tiles, current_stream()), "gsl_tiny_project_bwd")
-            return
         check(self.lib.gsl_fused_project_bwd(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
@@ -242,6 +231,15 @@ class _CtxRender(torch.autograd.Function):
         return (None, g["means"] if (full and ni[1]) else None, g["quats"] if (full and ni[2]) else None,
                 g["scales"] if (full and ni[3]) else None, g["opacities"] if (full and ni[4]) else None,
                 g["colors"] if (full and ni[5] and rc.rgb) else None, g["viewmat"] if ni[6] else None, None)
+
+
+def pack_pose_reduce(v_viewmat: Tensor, out16: Tensor, loss_partials: Optional[Tensor] = None) -> None:
+    """One rank's contribution to the per-iteration all-reduce: out16[0:12] = v_viewmat rows 0..2,
+    out16[12:14] = the sums of loss_partials[n,2] (or 0), written by a kernel of the library -- no torch op, so a
+    captured iteration holds this library's launches only."""
+    n = 0 if loss_partials is None else loss_partials.numel() // 2
+    check(load_library().gsl_pack_pose_reduce(ptr(v_viewmat), ptr(loss_partials), n, ptr(out16), current_stream()),
+          "gsl_pack_pose_reduce")
 
 
 def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, full: bool, steps: int = 20) -> Dict:

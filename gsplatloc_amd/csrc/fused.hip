@@ -239,16 +239,6 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Compositing.  256-thread workgroup per 16x16 tile, one wave64 per 8x8 quadrant.  A batch of
-// 256 splats is gathered once per workgroup into LDS; each wave then pulls 64 of them into
-// registers (one per lane), ballots the quadrant test and broadcasts the survivors lane by lane
-// with v_readlane (scalar operands) -- the per-splat inner loop touches neither LDS nor memory.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bcast(float v, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-
 // Lane select driven by a 64-bit scalar mask (v_cndmask_b32_e64 with an SGPR pair).  Measured on
 // MI355X: the VOP2 form that reads VCC issues ~5x slower than this form (9.5 vs 1.8 ns per
 // wave-instruction per SIMD), and hipcc picks the VCC form for plain ?: selects -- so the hot
@@ -264,330 +254,13 @@ __device__ __forceinline__ int sel64i(unsigned long long m, int t, int f) {
   return r;
 }
 
-template <int D>
-struct FStage {
-  float4 s0[256];
-  float4 s1[256];
-  float4 s2[(D >= 3) ? 256 : 1];
-};
-
-template <int D, bool ED>
-__global__ __launch_bounds__(256) void k_fraster_fwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
-  constexpr bool RGB = D >= 3;
-  constexpr bool DEPTH = (D == 1) || (D == 4);
-  __shared__ FStage<D> sb;
-  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
-  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  int j = qx + (lane & 7), i = qy + (lane >> 3);
-  float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
-  bool done = !inside;
-  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;  // quadrant centre; half extent of pixel centres = 3.5
-
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs > re) rs = re;
-  int nb = (int)((re - rs + 255) / 256);
-
-  float T = 1.f;
-  int cur_idx = 0;
-  float pix[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) pix[k] = 0.f;
-  unsigned long long donem = __ballot(done);  // per-lane "pixel finished" as a scalar mask
-
-  for (int b = 0; b < nb; ++b) {
-    if (__syncthreads_and(donem == ~0ull)) break;
-    long long bstart = rs + (long long)b * 256;
-    int bsize = (int)min((long long)256, re - bstart);
-    if (tid < bsize) {
-      int g = flatten_ids[bstart + tid];
-      sb.s0[tid] = GSL_Q(Q0, g);
-      sb.s1[tid] = GSL_Q(Q1, g);
-      if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
-    }
-    __syncthreads();
-    for (int c = 0; c < bsize && donem != ~0ull; c += 64) {
-      int e = c + lane;
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f);
-      if (e < bsize) {
-        a0 = sb.s0[e];
-        a1 = sb.s1[e];
-      }
-      unsigned long long m = __ballot(fabsf(a0.x - qcx) <= a1.w + 3.5f) & __ballot(fabsf(a0.y - qcy) <= a1.w + 3.5f);
-      while (m) {
-        int t = c + __ffsll((long long)m) - 1;
-        m &= m - 1;
-        // wave-uniform LDS address: one broadcast read per record, operands arrive in VGPRs
-        // (requesting the next survivor's records early was measured slower: more VGPRs, same issue rate)
-        float4 q0 = sb.s0[t], q1 = sb.s1[t];
-        float dx = q0.x - px, dy = q0.y - py;
-        float sigma = 0.5f * (q1.x * dx * dx + q1.z * dy * dy) + q1.y * dx * dy;
-        float alpha = fminf(GSL_ALPHA_MAX, q0.w * __expf(-sigma));
-        float nT = T * (1.f - alpha);
-        unsigned long long okm = __ballot(sigma >= 0.f) & __ballot(alpha >= GSL_ALPHA_MIN) & ~donem;
-        unsigned long long stopm = __ballot(nT <= GSL_T_STOP) & okm;
-        unsigned long long takem = okm & ~stopm;
-        float vis = sel64(takem, alpha * T, 0.f);
-        if (RGB) {
-          float4 q2 = sb.s2[t];
-          pix[0] += q2.x * vis; pix[1] += q2.y * vis; pix[2] += q2.z * vis;
-        }
-        if (DEPTH) pix[D - 1] += q0.z * vis;
-        cur_idx = sel64i(takem, (int)bstart + t, cur_idx);
-        T = sel64(takem, nT, T);
-        donem |= stopm;
-        if (donem == ~0ull) break;
-      }
-    }
-  }
-  if (inside) {
-    size_t pid = (size_t)i * W + j;
-    float A = 1.f - T;
-    alphas[pid] = A;
-    if (ED) pix[D - 1] = pix[D - 1] / fmaxf(A, 1e-10f);
-#pragma unroll
-    for (int k = 0; k < D; ++k) render[pid * D + k] = pix[k];
-    last_ids[pid] = cur_idx;
-  }
-}
-
-// 64-lane reduce-scatter of 32 per-lane values: after the call lanes 2v and 2v+1 both hold the
-// wave-wide sum of v[index v].  Steps: permlane32/16 swaps (cross-row), then DPP row mirrors and
-// quad permutes; 16+8 swaps, 24+4+2+1 adds/selects instead of 32 x 6 DPP adds.
-// v_permlane32_swap vdst, vsrc: lanes 32-63 of vdst trade places with lanes 0-31 of vsrc, so
-// afterwards vdst = [a.lo, b.lo] and vsrc = [a.hi, b.hi]; their sum gives the low half-wave
-// a[i]+a[i+32] and the high half-wave b[i-32]+b[i].  v_permlane16_swap does the same between
-// odd rows of vdst and even rows of vsrc.  Inline asm (with the 2 wait states the hazard rule
-// asks for after a VALU write) because both registers are outputs.
-__device__ __forceinline__ float swap_add32(float lo_keep, float hi_keep) {
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo_keep), "+v"(hi_keep));
-  return lo_keep + hi_keep;
-}
-__device__ __forceinline__ float swap_add16(float lo_keep, float hi_keep) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(lo_keep), "+v"(hi_keep));
-  return lo_keep + hi_keep;
-}
-__device__ __forceinline__ float reduce_scatter32(float (&v)[32], int lane) {
-  float a[16], b[8], c[4], d[2];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) a[k] = swap_add32(v[k], v[16 + k]);  // lanes <32: idx k, lanes >=32: idx 16+k
-#pragma unroll
-  for (int k = 0; k < 8; ++k) b[k] = swap_add16(a[k], a[8 + k]);    // odd rows keep the upper half
-  const unsigned long long B3 = 0xFF00FF00FF00FF00ull;  // lanes with bit 3 / 2 / 1 set
-  const unsigned long long B2 = 0xF0F0F0F0F0F0F0F0ull;
-  const unsigned long long B1 = 0xCCCCCCCCCCCCCCCCull;
-  (void)lane;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float lo = b[k] + dpp_get<0x140>(b[k]);          // row_mirror pairs lane i with 15-i
-    float hi = b[4 + k] + dpp_get<0x140>(b[4 + k]);
-    c[k] = sel64(B3, hi, lo);
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    float lo = c[k] + dpp_get<0x141>(c[k]);          // row_half_mirror pairs i with 7-i (per 8 lanes)
-    float hi = c[2 + k] + dpp_get<0x141>(c[2 + k]);
-    d[k] = sel64(B2, hi, lo);
-  }
-  float lo = d[0] + dpp_get<0x4E>(d[0]);             // quad_perm [2,3,0,1]
-  float hi = d[1] + dpp_get<0x4E>(d[1]);
-  float r = sel64(B1, hi, lo);
-  r += dpp_get<0xB1>(r);                             // quad_perm [1,0,3,2]
-  return r;
-}
-
-template <int D>
-struct FStageB {
-  static constexpr int A = 6 + D;   // v_xy 2, v_conic 3, v_opacity 1, v_colour D
-  static constexpr int AP = A | 1;  // odd LDS pitch
-  float4 s0[256];
-  float4 s1[256];
-  float4 s2[(D >= 3) ? 256 : 1];
-  int32_t id[256];
-  float acc[256 * AP];
-  uint16_t list[4][64];
-};
-
-// Batch loop of the compositing backward.  CG = number of colour channels that carry an upstream
-// gradient in this tile: D (all of them) or 1 (only the depth channel -- the situation of GsplatLoc's
-// depth + edge loss, /root/reference/src/my_gsplat/gs_trainer_total.py:126-150, detected per tile at
-// run time).  Per staged splat each lane needs, besides alpha and T,
-//     cdot = sum_k colour_k * v_C_k          (one scalar per lane and splat)
-//     Bp   = sum_{splats behind} fac * cdot - T_final * v_A   (one running scalar per lane)
-// so that v_alpha = T * cdot - ra * Bp; the per-channel "buffer" of the textbook replay folds into Bp.
-template <int D, int CG>
-__device__ __forceinline__ void fraster_bwd_body(
-    FStageB<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
-    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
-    float px, float py, float qcx, float qcy, bool inside, int bin_final, int wave_final, float T_final,
-    const float (&vc)[D], float va) {
-  constexpr bool RGB = D >= 3;
-  constexpr bool DEPTH = (D == 1) || (D == 4);
-  constexpr int A = FStageB<D>::A;    // accumulator row layout: [xy 2][conic 3][opacity 1][colour D]
-  constexpr int AP = FStageB<D>::AP;
-  constexpr int AC = 6 + CG;          // values reduced per splat in this variant
-  constexpr int G = 32 / AC;          // splats per reduce-scatter
-  int lane = tid & 63, wv = tid >> 6;
-  float T = T_final;
-  float Bp = -T_final * va;
-  unsigned long long insidem = __ballot(inside);
-  // after the reduce-scatter lanes 2v and 2v+1 hold value v = (splat rh of the group, component rc)
-  int rv = lane >> 1, rh = rv / AC, rc = rv - rh * AC;
-  int rk = (rc < 6) ? rc : ((CG == D) ? rc : (6 + D - 1));  // position in the accumulator row
-  bool writer = !(lane & 1) && rh < G;
-  unsigned long long hmask[G];
-#pragma unroll
-  for (int hh = 0; hh < G; ++hh) hmask[hh] = __ballot(rh == hh);
-
-  for (int b = 0; b < nb; ++b) {
-    long long bend = re - 1 - (long long)b * 256;  // slot t <-> absolute index bend - t (back to front)
-    int bsize = (int)min((long long)256, bend + 1 - rs);
-    __syncthreads();
-    if (tid < bsize) {
-      int g = flatten_ids[bend - tid];
-      sb.id[tid] = g;
-      sb.s0[tid] = GSL_Q(Q0, g);
-      sb.s1[tid] = GSL_Q(Q1, g);
-      if (RGB && CG == D) sb.s2[tid] = GSL_Q(Q2, g);
-    }
-#pragma unroll
-    for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
-    __syncthreads();
-    int t_first = (int)max((long long)0, bend - (long long)wave_final);
-    for (int c = (t_first / 64) * 64; c < bsize; c += 64) {
-      int e = c + lane;
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, -1.f);
-      if (e < bsize && e >= t_first) {
-        a0 = sb.s0[e];
-        a1 = sb.s1[e];
-      }
-      unsigned long long m = __ballot(fabsf(a0.x - qcx) <= a1.w + 3.5f) & __ballot(fabsf(a0.y - qcy) <= a1.w + 3.5f);
-      while (m) {
-        float vals[32];
-#pragma unroll
-        for (int k = G * AC; k < 32; ++k) vals[k] = 0.f;
-        int slot[G];
-#pragma unroll
-        for (int h = 0; h < G; ++h) {
-          // next staged splat that some pixel of this quadrant actually composited
-          unsigned long long validm = 0, capm = 0;
-          int t = 0;
-          float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
-          float dx = 0.f, dy = 0.f, gx = 0.f, gy = 0.f, vis = 0.f, alpha = 0.f;
-          while (m && !validm) {
-            t = c + __ffsll((long long)m) - 1;
-            m &= m - 1;
-            q0 = sb.s0[t];
-            q1 = sb.s1[t];
-            dx = q0.x - px; dy = q0.y - py;
-            gx = q1.x * dx + q1.y * dy;   // d sigma / d dx
-            gy = q1.y * dx + q1.z * dy;   // d sigma / d dy
-            float sigma = 0.5f * (dx * gx + dy * gy);
-            vis = __expf(-sigma);
-            float opv = q0.w * vis;
-            alpha = fminf(GSL_ALPHA_MAX, opv);
-            validm = insidem & __ballot((int)(bend - t) <= bin_final) & __ballot(sigma >= 0.f) &
-                     __ballot(alpha >= GSL_ALPHA_MIN);
-            capm = __ballot(opv <= GSL_ALPHA_MAX);
-          }
-          if (!validm) {
-            slot[h] = -1;
-#pragma unroll
-            for (int k = 0; k < AC; ++k) vals[h * AC + k] = 0.f;
-            continue;
-          }
-          slot[h] = t;
-          // lanes that did not composite this splat run with alpha = 0: ra = 1, fac = 0, so T and Bp stay
-          // untouched and every gradient term is zero without per-value selects
-          float am = sel64(validm, alpha, 0.f);
-          float ra = __builtin_amdgcn_rcpf(1.f - am);
-          T *= ra;
-          float fac = am * T;
-          float cdot;
-          if (CG == D) {
-            float colv[D];
-            if (RGB) {
-              float4 q2 = sb.s2[t];
-              colv[0] = q2.x; colv[1] = q2.y; colv[2] = q2.z;
-            }
-            if (DEPTH) colv[D - 1] = q0.z;
-            cdot = 0.f;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-              cdot += colv[k] * vc[k];
-              vals[h * AC + 6 + k] = fac * vc[k];
-            }
-          } else {
-            cdot = q0.z * vc[D - 1];
-            vals[h * AC + 6] = fac * vc[D - 1];
-          }
-          float v_alpha = T * cdot - ra * Bp;
-          Bp += fac * cdot;
-          float vism = sel64(validm & capm, vis, 0.f);  // alpha clamped at 0.999 => no geometric gradient
-          float v_sigma = -q0.w * vism * v_alpha;
-          float hs = 0.5f * v_sigma;
-          vals[h * AC + 0] = v_sigma * gx;
-          vals[h * AC + 1] = v_sigma * gy;
-          vals[h * AC + 2] = hs * dx * dx;
-          vals[h * AC + 3] = v_sigma * dx * dy;
-          vals[h * AC + 4] = hs * dy * dy;
-          vals[h * AC + 5] = vism * v_alpha;
-        }
-        if (slot[0] < 0) break;  // nothing left in this chunk for this quadrant
-#if defined(GSL_ABLATE) && GSL_ABLATE >= 3
-        float r = vals[0] + vals[9] + vals[19] + vals[29];  // timing ablation: no cross-lane reduction (results wrong)
-#else
-        float r = reduce_scatter32(vals, lane);
-#endif
-        int sl = -1;
-#pragma unroll
-        for (int hh = 0; hh < G; ++hh) sl = sel64i(hmask[hh], slot[hh], sl);
-#if defined(GSL_ABLATE) && GSL_ABLATE >= 2
-        if (writer && sl >= 0) sb.acc[sl * AP + rk] = r;  // timing ablation: plain LDS store (results wrong)
-#else
-        if (writer && sl >= 0) atomicAdd(&sb.acc[sl * AP + rk], r);
-#endif
-      }
-    }
-    __syncthreads();
-    // Flush the batch: pack non-zero slots so that 16 consecutive lanes add one Gaussian's 64-byte row.
-    {
-      bool nz = false;
-      if (tid < bsize) {
-#pragma unroll
-        for (int k = 0; k < A; ++k) nz = nz || (sb.acc[tid * AP + k] != 0.f);
-      }
-      unsigned long long mask = __ballot(nz);
-      int cnt = __popcll(mask);
-      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-      __syncthreads();
-      int f = lane & 15;
-      for (int i0 = 0; i0 < cnt; i0 += 4) {
-        int gi = i0 + (lane >> 4);
-        if (gi < cnt && f < A) {
-          int sl = sb.list[wv][gi];
-          size_t g = (size_t)sb.id[sl];
-#if defined(GSL_ABLATE) && (GSL_ABLATE == 1 || GSL_ABLATE >= 3)
-          vacc[g * 16 + f] = sb.acc[sl * AP + f];  // timing ablation: plain global store (results wrong)
-#else
-          atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
-#endif
-        }
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Compositing backward with the per-splat pixel reduction on the matrix cores.
-// Hardware ablation of k_fraster_bwd (profiles/r02_backward_ablation.txt): its atomics are free, its 64-lane
-// reduce-scatter of 7-10 values per splat is 38 % of the kernel.  Every one of those sums is linear in two per-pixel
+// Compositing backward.  256-thread workgroup per 16x16 tile, one wave64 per 8x8 quadrant; a batch of list entries
+// is gathered once per workgroup into LDS, each wave ballots the quadrant test over 64 of them and walks the
+// survivors back to front, broadcasting each record from LDS (wave-uniform address).  The per-splat pixel sums run
+// on the matrix cores: hardware ablation of the previous build (profiles/r02_backward_ablation.txt) showed its
+// atomics to be free and its 64-lane DPP reduce-scatter of 7-10 values per splat to cost a quarter of the kernel.
+// Every one of those sums is linear in two per-pixel
 // scalars of the (pixel, splat) pair,
 //     w = vis * v_alpha (0 where alpha is clamped or the pixel did not composite the splat)    f = alpha * T,
 // with per-pixel weights that do not depend on the splat once dx = X - px is expanded around the tile centre:
@@ -871,7 +544,7 @@ __global__ __launch_bounds__(256) void k_mraster_bwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc) {
+    float* __restrict__ vacc, int row0, int row1) {
   __shared__ FStageM<D> sb;
   __shared__ int s_final[4];
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
@@ -880,7 +553,7 @@ __global__ __launch_bounds__(256) void k_mraster_bwd(
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
   int j = qx + (lane & 7), i = qy + (lane >> 3);
   float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
+  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
   float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;
   float tcx = (float)(txi * 16) + 8.f, tcy = (float)(tyi * 16) + 8.f;
 
@@ -919,71 +592,6 @@ __global__ __launch_bounds__(256) void k_mraster_bwd(
   else
     mraster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
                            bin_final, wave_final, T_final, vc, va);
-}
-
-// Build variant -DGSL_BWD_WAVES=n asks the register allocator for n waves per SIMD (the default build lands at
-// 120 VGPRs = 4 waves; 5 waves = 96 VGPRs costs 13 spilled registers).  Unset in the measured library.
-#ifdef GSL_BWD_WAVES
-#define GSL_BWD_ATTR __attribute__((amdgpu_waves_per_eu(GSL_BWD_WAVES, GSL_BWD_WAVES)))
-#else
-#define GSL_BWD_ATTR
-#endif
-
-template <int D, bool ED>
-__global__ __launch_bounds__(256) GSL_BWD_ATTR void k_fraster_bwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
-    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc) {
-  __shared__ FStageB<D> sb;
-  __shared__ int s_final[4];
-  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
-  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  int j = qx + (lane & 7), i = qy + (lane >> 3);
-  float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
-  float qcx = (float)qx + 4.f, qcy = (float)qy + 4.f;
-
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs >= re) return;
-
-  size_t pid = inside ? ((size_t)i * W + j) : 0;
-  float Aimg = inside ? alphas[pid] : 0.f;
-  float T_final = 1.f - Aimg;
-  int bin_final = inside ? last_ids[pid] : -1;
-  float vc[D];
-  float va = inside ? v_alphas[pid] : 0.f;
-#pragma unroll
-  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
-  if (ED && inside) {
-    // render[..., D-1] = C_depth / max(A, 1e-10): chain to the accumulated depth and to alpha
-    float dn = render[pid * D + (D - 1)];
-    float vd = vc[D - 1];
-    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
-    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
-  }
-  int wave_final = bin_final;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
-  if (lane == 0) s_final[wv] = wave_final;
-  bool rgb_grad = false;
-  if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
-  int any_rgb = __syncthreads_or(rgb_grad);
-  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
-  // nothing behind block_final was composited by any pixel of the tile: start there
-  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
-  if (rs >= re) return;
-  int nb = (int)((re - rs + 255) / 256);
-  if (D == 4 && !any_rgb)
-    fraster_bwd_body<D, 1>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, inside, bin_final,
-                           wave_final, T_final, vc, va);
-  else
-    fraster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, inside, bin_final,
-                           wave_final, T_final, vc, va);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1228,76 +836,29 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
   else if (D == 4) { if (ED) CALL(4, true); else CALL(4, false); } \
   else return GSL_ERR_BAD_ARG;
 
-extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
-                                    int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                                    float* render, float* alphas, int32_t* last_ids, void* stream) {
-  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0)
-    return GSL_ERR_BAD_ARG;
-  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
-  if (!tile_offsets || !render || !alphas || !last_ids) return GSL_ERR_BAD_ARG;
-  if (capacity > 0 && (!Q0 || !Q1 || !flatten_ids)) return GSL_ERR_BAD_ARG;
-  if (channels >= 3 && capacity > 0 && !Q2) return GSL_ERR_BAD_ARG;
-  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
-  if (ty0 == ty1) return GSL_OK;
-  hipStream_t st = (hipStream_t)stream;
-  int nblk = (ty1 - ty0) * tile_w;
-#define CALL_FF(DD, EE)                                                                                       \
-  hipLaunchKernelGGL((gsl::k_fraster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
-                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids)
-  GSL_F_DISPATCH(channels, ed, CALL_FF)
-#undef CALL_FF
-  GSL_CHECK_LAUNCH();
-  return GSL_OK;
-}
-
+// Compositing backward (k_mraster_bwd): quadrant walk, per-splat pixel sums on the matrix cores.  Adds into vacc.
+// Pixel rows outside [row0, row1) are not touched (strip rendering with a one-pixel halo).
 extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
-                                    int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                                    const float* render, const float* alphas, const int32_t* last_ids,
-                                    const float* v_render, const float* v_alphas, float* vacc, void* stream) {
-  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0)
-    return GSL_ERR_BAD_ARG;
-  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
-  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
-  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
-  if (capacity == 0 || ty0 == ty1) return GSL_OK;
-  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  int nblk = (ty1 - ty0) * tile_w;
-#define CALL_FB(DD, EE)                                                                                       \
-  hipLaunchKernelGGL((gsl::k_fraster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
-                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
-  GSL_F_DISPATCH(channels, ed, CALL_FB)
-#undef CALL_FB
-  GSL_CHECK_LAUNCH();
-  return GSL_OK;
-}
-
-// Same contract as gsl_fused_raster_bwd; the per-splat pixel sums run on the matrix cores (k_mraster_bwd).
-extern "C" int gsl_mfma_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                                    int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                    const float* render, const float* alphas, const int32_t* last_ids,
-                                   const float* v_render, const float* v_alphas, float* vacc, void* stream) {
+                                   const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
+                                   void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0)
+      capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
   if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
-  if (capacity == 0 || ty0 == ty1) return GSL_OK;
+  if (capacity == 0 || ty0 == ty1 || row0 == row1) return GSL_OK;
   if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
 #define CALL_MB(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,    \
+                     row0, row1)
   GSL_F_DISPATCH(channels, ed, CALL_MB)
 #undef CALL_MB
   GSL_CHECK_LAUNCH();
@@ -1344,23 +905,5 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
     GSL_CHECK_LAUNCH();
   }
-  return GSL_OK;
-}
-
-// ---- self-test hook for the 64-lane reduce-scatter (used by tests/test_gpu_parity.py) ----
-namespace gsl {
-__global__ void k_debug_reduce_scatter(const float* __restrict__ in /*[64][32]*/, float* __restrict__ out /*[64]*/) {
-  int lane = threadIdx.x;
-  float v[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) v[k] = in[lane * 32 + k];
-  out[lane] = reduce_scatter32(v, lane);
-}
-}  // namespace gsl
-
-extern "C" int gsl_debug_reduce_scatter(const float* in, float* out, void* stream) {
-  if (!in || !out) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_debug_reduce_scatter, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
-  GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

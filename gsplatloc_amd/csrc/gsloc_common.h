@@ -92,29 +92,11 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
   return c;
 }
 
-// Per-Gaussian records Q0/Q1/Q2 (float4 each) are indexed as Qk[g * GSL_QS].  GSL_QS = 1: three separate arrays
-// (the measured layout).  GSL_QS = 4 (build variant libgsloc_hip_aos.so): the three pointers address one
-// interleaved array of 64-byte rows [Q0 | Q1 | Q2 | pad], so a gather of one splat touches one 128-byte line
-// instead of three.
-#ifndef GSL_QS
-#define GSL_QS 1
-#endif
-#define GSL_Q(arr, g) (arr)[(g) * GSL_QS]
-
-// Workgroup -> tile of the compositing kernels.  The dispatcher deals consecutive workgroups to the 8 XCDs in turn,
-// and every XCD has its own L2, so with the identity map (measured layout) the four tiles a splat overlaps are
-// gathered into up to four L2s.  Build variant -DGSL_XCD_REMAP: XCD x (workgroups x, x+8, x+16, ...) walks ONE
-// contiguous span of the strip's tiles, so neighbouring tiles share an L2.  A bijection of [0, n) for any n.
-#ifdef GSL_XCD_REMAP
-__device__ __forceinline__ int tile_of_block(int b, int n) {
-  int x = b & 7, k = b >> 3;
-  int q = n >> 3, rem = n & 7;
-  return x * q + (x < rem ? x : rem) + k;  // spans of q (+1 for the first n%8 XCDs) tiles
-}
-#define GSL_TILE_OF_BLOCK() tile_of_block((int)blockIdx.x, (int)gridDim.x)
-#else
+// Per-Gaussian records Q0/Q1/Q2: three arrays of float4.  (Measured alternatives, profiles/r02_backward_ablation.txt:
+// one interleaved array of 64-byte rows made the random-order forward 10 % faster and projection / binning slower,
+// no net gain; a workgroup -> tile map that gives each XCD one contiguous span of tiles changed nothing.)
+#define GSL_Q(arr, g) (arr)[(g)]
 #define GSL_TILE_OF_BLOCK() blockIdx.x
-#endif
 
 // DPP lane exchange (no LDS traffic).  Lanes a row_mask disables contribute 0.
 template <int CTRL, int ROW_MASK = 0xF>

@@ -101,7 +101,8 @@ template <int D, bool ED>
 __global__ __launch_bounds__(256) void k_praster_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+    int row0, int row1) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ PStage<D> sb;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
   int j = qx + (lane & 7), i = qy + (lane >> 3);
   float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
+  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
   bool done = !inside;
 
   long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
@@ -221,280 +222,14 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Backward.  ds_add_f32 issues at ~80 ns per wave-instruction per CU on MI355X (scripts/ubench/ldsatom.hip),
-// so the per-lane walk cannot add into shared accumulators.  Two phases per round of 16 candidates:
-//   phase 1 (lane = pixel): walk the own candidate bits back to front, keep T and the running scalar Bp,
-//            and leave per (pixel, candidate) just  w = vis * v_alpha  (0 when alpha is clamped or the
-//            splat was not composited) and  fac = alpha * T  in an LDS slab rec[candidate][pixel];
-//   phase 2 (4 lanes = one candidate): walk the pixels of the candidate's box, rebuild dx, dy and the
-//            gradient direction from the candidate's own record, and sum
-//            v_xy, v_conic, v_opacity, v_colour over the pixels; two quad DPP adds fold the 4 lanes.
-// Per-(quadrant, candidate) totals leave the workgroup as packed 64-byte atomic rows.
-// ---------------------------------------------------------------------------------------------------
-template <int D, int CG>
-struct PStageB {
-  static constexpr bool RGBS = (D >= 3) && (CG == D);
-  float4 s0[256];
-  float4 s1[256];
-  float4 s2[RGBS ? 256 : 1];
-  uint16_t qlist[4][256];
-  int qcnt[4][4];
-  int32_t id[256];
-  float2 rec[4][16][64];      // [wave][candidate of the round][pixel lane] = (w, fac)
-  uint16_t pmask[4][64];      // candidate bits of the round per pixel lane
-  uint16_t box[4][64];        // candidate boxes of the chunk: lox | hix<<4 | loy<<8 | hiy<<12
-  float vcs[4][64][CG];       // upstream colour gradients per pixel lane
-  float tot[4][16][16];       // per-candidate totals of the round, accumulator-row layout
-};
-
-template <int D, int CG>
-__device__ __forceinline__ void praster_bwd_body(
-    PStageB<D, CG>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
-    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
-    int txi, int tyi, int qx, int qy, float px, float py, bool inside, int bin_final, int wave_final, float T_final,
-    const float (&vc)[D], float va) {
-  constexpr bool RGB = D >= 3;
-  constexpr bool DEPTH = (D == 1) || (D == 4);
-  constexpr bool RGBS = PStageB<D, CG>::RGBS;
-  constexpr int A = 6 + D;  // accumulator row: [v_xy 2][v_conic 3][v_opacity 1][v_colour D]
-  int lane = tid & 63, wv = tid >> 6;
-  float T = T_final;
-  float Bp = -T_final * va;  // running  sum_behind(fac * cdot) - T_final * v_A   (see fused.hip)
-  // this pixel's upstream colour gradients, for the candidate-major phase
-  if (CG == D) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) sb.vcs[wv][lane][k] = vc[k];
-  } else {
-    sb.vcs[wv][lane][0] = vc[D - 1];
-  }
-  int c2 = lane >> 2, part = lane & 3;  // phase-2 role: candidate of the round, quarter of its rows
-
-  for (int b = 0; b < nb; ++b) {
-    long long bend = re - 1 - (long long)b * 256;  // slot t <-> absolute index bend - t (back to front)
-    int bsize = (int)min((long long)256, bend + 1 - rs);
-    __syncthreads();
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
-    if (tid < bsize) {
-      int g = flatten_ids[bend - tid];
-      sb.id[tid] = g;
-      r0 = GSL_Q(Q0, g);
-      r1 = GSL_Q(Q1, g);
-      sb.s0[tid] = r0;
-      sb.s1[tid] = r1;
-      if (RGBS) sb.s2[tid] = GSL_Q(Q2, g);
-    }
-    int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
-    // slots below t_first hold splats behind everything this quadrant composited
-    int t_first = (int)max((long long)0, bend - (long long)wave_final);
-    int t_lane = inside ? (int)max((long long)0, bend - (long long)bin_final) : 1 << 30;  // first slot of this pixel
-    for (int c = 0; c < n; c += 64) {
-      int e = c + lane;
-      int lox = 1, hix = 0, loy = 1, hiy = 0;
-      if (e < n) {
-        int t = sb.qlist[wv][e];
-        if (t >= t_first) {
-          float4 a0 = sb.s0[t];
-          float r = sb.s1[t].w;
-          box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
-          box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
-        }
-      }
-      sb.box[wv][lane] = (uint16_t)((lox & 15) | ((hix & 15) << 4) | ((loy & 15) << 8) | ((hiy & 15) << 12));
-      unsigned mlo, mhi;
-      pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
-      unsigned long long m64 = ((unsigned long long)mhi << 32) | mlo;
-      if (!__ballot(m64 != 0)) continue;
-#pragma unroll 1
-      for (int rnd = 0; rnd < 4; ++rnd) {
-        unsigned m = (unsigned)(m64 >> (16 * rnd)) & 0xFFFFu;
-        if (!__ballot(m != 0)) continue;
-        int cbase = c + 16 * rnd;
-        sb.pmask[wv][lane] = (uint16_t)m;
-        // ---- phase 1: lane = pixel
-        while (__ballot(m != 0)) {
-          if (m != 0) {
-            int bit = __ffs((int)m) - 1;
-            m &= m - 1;
-            int t = sb.qlist[wv][cbase + bit];
-            float w = 0.f, fac = 0.f;
-            if (t >= t_lane) {
-              float4 q0 = sb.s0[t], q1 = sb.s1[t];
-              float dx = q0.x - px, dy = q0.y - py;
-              float gx = q1.x * dx + q1.y * dy;
-              float gy = q1.y * dx + q1.z * dy;
-              float sigma = 0.5f * (dx * gx + dy * gy);
-              float vis = __expf(-sigma);
-              float opv = q0.w * vis;
-              float alpha = fminf(GSL_ALPHA_MAX, opv);
-              if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
-                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-                T *= ra;
-                fac = alpha * T;
-                float cdot;
-                if (CG == D) {
-                  cdot = 0.f;
-                  if (RGB) {
-                    float4 q2 = sb.s2[t];
-                    cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
-                  }
-                  if (DEPTH) cdot += q0.z * vc[D - 1];
-                } else {
-                  cdot = q0.z * vc[D - 1];
-                }
-                float v_alpha = T * cdot - ra * Bp;
-                Bp += fac * cdot;
-                if (opv <= GSL_ALPHA_MAX) w = vis * v_alpha;  // alpha clamped at 0.999 => no geometric gradient
-              }
-            }
-            sb.rec[wv][bit][lane] = make_float2(w, fac);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase 2: 4 lanes = one candidate of the round
-        float acc[A];
-#pragma unroll
-        for (int k = 0; k < A; ++k) acc[k] = 0.f;
-        int ci = cbase + c2;
-        int gsl_t = 0;
-        if (ci < n) {
-          unsigned bx = sb.box[wv][16 * rnd + c2];
-          int blox = bx & 15, bhix = (bx >> 4) & 15, bloy = (bx >> 8) & 15, bhiy = (bx >> 12) & 15;
-          gsl_t = sb.qlist[wv][ci];
-          float4 q0 = sb.s0[gsl_t], q1 = sb.s1[gsl_t];
-          for (int row = bloy + part; row <= bhiy; row += 4) {
-            for (int col = blox; col <= bhix; ++col) {
-              int pl = row * 8 + col;
-              if ((sb.pmask[wv][pl] >> c2) & 1) {
-                float2 wf = sb.rec[wv][c2][pl];
-                float dx = q0.x - ((float)(qx + col) + 0.5f), dy = q0.y - ((float)(qy + row) + 0.5f);
-                float gx = q1.x * dx + q1.y * dy;
-                float gy = q1.y * dx + q1.z * dy;
-                float v_sigma = -q0.w * wf.x;
-                float hs = 0.5f * v_sigma;
-                acc[0] += v_sigma * gx;
-                acc[1] += v_sigma * gy;
-                acc[2] += hs * dx * dx;
-                acc[3] += v_sigma * dx * dy;
-                acc[4] += hs * dy * dy;
-                acc[5] += wf.x;
-                if (CG == D) {
-#pragma unroll
-                  for (int k = 0; k < D; ++k) acc[6 + k] += wf.y * sb.vcs[wv][pl][k];
-                } else {
-                  acc[6 + D - 1] += wf.y * sb.vcs[wv][pl][0];
-                }
-              }
-            }
-          }
-        }
-        bool nzl = false;
-#pragma unroll
-        for (int k = 0; k < A; ++k) {
-          float v = acc[k];
-          v += dpp_get<0xB1>(v);  // quad_perm [1,0,3,2]
-          v += dpp_get<0x4E>(v);  // quad_perm [2,3,0,1]: all 4 lanes of the candidate hold its total
-          acc[k] = v;
-          nzl = nzl || (v != 0.f);
-        }
-        if (part == 0) {
-#pragma unroll
-          for (int k = 0; k < A; ++k) sb.tot[wv][c2][k] = acc[k];
-        }
-        unsigned long long nzm = __ballot(nzl && part == 0);  // bit 4*c2 set <=> candidate c2 has a gradient
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // flush: 16 consecutive lanes add one candidate's 64-byte accumulator row
-        int f = lane & 15;
-        while (nzm) {
-          // up to 4 candidates per trip
-          int cand = -1;
-          unsigned long long mm = nzm;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            int bpos = mm ? (__ffsll((long long)mm) - 1) : -1;
-            if (mm) mm &= mm - 1;
-            if ((lane >> 4) == k) cand = bpos >> 2;
-          }
-          nzm = mm;
-          if (cand >= 0 && f < A) {
-            int t = sb.qlist[wv][cbase + cand];
-            size_t g = (size_t)sb.id[t];
-            atomicAdd(&vacc[g * 16 + f], sb.tot[wv][cand][f]);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-}
-
-template <int D, bool ED>
-__global__ __launch_bounds__(256) void k_praster_bwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
-    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc) {
-  // one LDS image, viewed through whichever variant (all channels / depth-only gradient) this tile runs
-  __shared__ __attribute__((aligned(16))) unsigned char sraw[sizeof(PStageB<D, D>) > sizeof(PStageB<D, 1>)
-                                                                 ? sizeof(PStageB<D, D>) : sizeof(PStageB<D, 1>)];
-  __shared__ int s_final[4];
-  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
-  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  int j = qx + (lane & 7), i = qy + (lane >> 3);
-  float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
-
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs >= re) return;
-
-  size_t pid = inside ? ((size_t)i * W + j) : 0;
-  float Aimg = inside ? alphas[pid] : 0.f;
-  float T_final = 1.f - Aimg;
-  int bin_final = inside ? last_ids[pid] : -1;
-  float vc[D];
-  float va = inside ? v_alphas[pid] : 0.f;
-#pragma unroll
-  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
-  if (ED && inside) {
-    float dn = render[pid * D + (D - 1)];
-    float vd = vc[D - 1];
-    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
-    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
-  }
-  int wave_final = bin_final;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
-  if (lane == 0) s_final[wv] = wave_final;
-  bool rgb_grad = false;
-  if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
-  int any_rgb = __syncthreads_or(rgb_grad);
-  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
-  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
-  if (rs >= re) return;
-  int nb = (int)((re - rs + 255) / 256);
-  if (D == 4 && !any_rgb)
-    praster_bwd_body<D, 1>(*reinterpret_cast<PStageB<D, 1>*>(sraw), Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid,
-                           txi, tyi, qx, qy, px, py, inside, bin_final, wave_final, T_final, vc, va);
-  else
-    praster_bwd_body<D, D>(*reinterpret_cast<PStageB<D, D>*>(sraw), Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid,
-                           txi, tyi, qx, qy, px, py, inside, bin_final, wave_final, T_final, vc, va);
-}
-
-// ---------------------------------------------------------------------------------------------------
 // "Tiny splat" backward (every r_cull < 2 px: the alpha >= 1/255 disc covers at most 4x4 pixel centres --
 // the situation of GsplatLoc's as-coded kNN scales, where every splat is the 0.3 px^2 blur).
 // Pass 1 (this kernel, lane = pixel): the back-to-front walk of the px scheme; per composited
 // (pixel, splat) it stores  (w, fac) = (vis * v_alpha [0 when alpha is clamped], alpha * T)  into the
 // splat's own 4x4 slab  trec[g][row - r0][col - c0]  (plain 8-byte stores, no atomics, no reduction), and
 // every pixel leaves its (expected-depth-chained) upstream gradient in vcT[H,W,D].
-// Pass 2 lives in the per-Gaussian projection backward (fused.hip, k_fproject_bwd<.., TINY>): it reads the
-// slab of its Gaussian, rebuilds dx, dy from the Gaussian's own record and sums the 16 slots.
+// Pass 2 is k_tiny_gather below: it reads the slab of its Gaussian, rebuilds dx, dy from the Gaussian's own record
+// and sums the 16 slots into the Gaussian's gradient row.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tiny_origin(float centre, float r) {  // first pixel index within r of centre
   return (int)ceilf(centre - r - 0.5f);
@@ -516,7 +251,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float2* __restrict__ trec, float* __restrict__ vcT) {
+    float2* __restrict__ trec, float* __restrict__ vcT, int row0, int row1, int32_t* __restrict__ flags) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ TStage<D> sb;
@@ -527,7 +262,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
   int j = qx + (lane & 7), i = qy + (lane >> 3);
   float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
+  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
   size_t pid = inside ? ((size_t)i * W + j) : 0;
   float Aimg = inside ? alphas[pid] : 0.f;
   float T_final = 1.f - Aimg;
@@ -625,6 +360,8 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
                 int cc = j - tiny_origin(q0.x, q1.w), rr = i - tiny_origin(q0.y, q1.w);
                 if ((unsigned)cc < 4u && (unsigned)rr < 4u)
                   trec[(size_t)sb.id[t] * 16 + rr * 4 + cc] = make_float2(w, fac);
+                else if (flags)
+                  flags[0] = 1;  // sticky: the splat outgrew its 4x4 slab (r_cull >= 2 px); polled by the host
               }
             }
           }
@@ -634,401 +371,84 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
   }
 }
 
-// Pass 2: 16 lanes (one DPP row) per Gaussian, one lane per slab slot; row reduction; the Gaussian's
-// 64-byte gradient row is written whole (plain stores) and the slab is cleared.
+// Pass 2: four lanes per Gaussian.  Lane r of a quad owns slab row r -- four (w, alpha*T) records, 32 contiguous
+// bytes, two 16-byte loads -- and accumulates the row's gradient terms in registers; two quad-permute DPP adds fold
+// the four rows; the Gaussian's 64-byte gradient row is written whole (plain stores) and the slab is cleared.
+// (Measured against the first version with one lane per slab slot: 168 vs 195 us for the tiny backward at
+// sigma -> 0, profiles/r02_backward_ablation.txt.)
 template <int D>
 __global__ __launch_bounds__(256) void k_tiny_gather(const float4* __restrict__ Q0, const float4* __restrict__ Q1,
-                                                     const int32_t* __restrict__ radii, int N, int W, int H,
-                                                     float2* __restrict__ trec, const float* __restrict__ vcT,
-                                                     float4* __restrict__ vacc) {
+                                                      const int32_t* __restrict__ radii, int N, int W, int H,
+                                                      float4* __restrict__ trec, const float* __restrict__ vcT,
+                                                      float4* __restrict__ vacc) {
   constexpr int A = 6 + D;
-  int gid = (blockIdx.x * 256 + threadIdx.x) >> 4, s = threadIdx.x & 15;
+  int t = blockIdx.x * 256 + threadIdx.x;
+  int gid = t >> 2, r = t & 3;
   bool live = gid < N && radii[gid] > 0;
   float v[A];
 #pragma unroll
   for (int k = 0; k < A; ++k) v[k] = 0.f;
   if (live) {
-    float2 wf = trec[(size_t)gid * 16 + s];
-    if (wf.x != 0.f || wf.y != 0.f) {
-      trec[(size_t)gid * 16 + s] = make_float2(0.f, 0.f);
-      float4 q0 = GSL_Q(Q0, gid), qc = GSL_Q(Q1, gid);
-      int pcol = tiny_origin(q0.x, qc.w) + (s & 3), prow = tiny_origin(q0.y, qc.w) + (s >> 2);
-      float dx = q0.x - ((float)pcol + 0.5f), dy = q0.y - ((float)prow + 0.5f);
-      float gx = qc.x * dx + qc.y * dy, gy = qc.y * dx + qc.z * dy;
-      float v_sigma = -q0.w * wf.x, hs = 0.5f * v_sigma;
-      v[0] = v_sigma * gx; v[1] = v_sigma * gy;
-      v[2] = hs * dx * dx; v[3] = v_sigma * dx * dy; v[4] = hs * dy * dy;
-      v[5] = wf.x;
-      if (wf.y != 0.f && (unsigned)pcol < (unsigned)W && (unsigned)prow < (unsigned)H) {
-        size_t pid = (size_t)prow * W + pcol;
+    float4* row = trec + (size_t)gid * 8 + 2 * r;  // slab = 16 float2 = 8 float4; row r = float4 2r, 2r+1
+    float4 lo = row[0], hi = row[1];
+    float w[4] = {lo.x, lo.z, hi.x, hi.z}, f[4] = {lo.y, lo.w, hi.y, hi.w};
+    bool any = false;
 #pragma unroll
-        for (int k = 0; k < D; ++k) v[6 + k] = wf.y * vcT[pid * D + k];
+    for (int c = 0; c < 4; ++c) any = any || (w[c] != 0.f) || (f[c] != 0.f);
+    if (any) {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      row[0] = z;
+      row[1] = z;
+      float4 q0 = GSL_Q(Q0, gid), qc = GSL_Q(Q1, gid);
+      int pcol0 = tiny_origin(q0.x, qc.w), prow = tiny_origin(q0.y, qc.w) + r;
+      float dy = q0.y - ((float)prow + 0.5f);
+      bool row_in = (unsigned)prow < (unsigned)H;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (w[c] != 0.f || f[c] != 0.f) {
+          int pcol = pcol0 + c;
+          float dx = q0.x - ((float)pcol + 0.5f);
+          float gx = qc.x * dx + qc.y * dy, gy = qc.y * dx + qc.z * dy;
+          float v_sigma = -q0.w * w[c], hs = 0.5f * v_sigma;
+          v[0] += v_sigma * gx; v[1] += v_sigma * gy;
+          v[2] += hs * dx * dx; v[3] += v_sigma * dx * dy; v[4] += hs * dy * dy;
+          v[5] += w[c];
+          if (f[c] != 0.f && row_in && (unsigned)pcol < (unsigned)W) {
+            size_t pid = (size_t)prow * W + pcol;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v[6 + k] += f[c] * vcT[pid * D + k];
+          }
+        }
       }
     }
   }
 #pragma unroll
   for (int k = 0; k < A; ++k) {
     float x = v[k];
-    x += dpp_get<0xB1>(x);   // quad_perm [1,0,3,2]
-    x += dpp_get<0x4E>(x);   // quad_perm [2,3,0,1]
-    x += dpp_get<0x141>(x);  // row_half_mirror
-    x += dpp_get<0x140>(x);  // row_mirror: every lane of the 16-lane row holds the Gaussian's total
+    x += dpp_get<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_get<0x4E>(x);  // quad_perm [2,3,0,1]: every lane of the quad holds the Gaussian's total
     v[k] = x;
   }
   if (live) {
     float pad[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) pad[k] = (k < A) ? v[k] : 0.f;
-    if (s == 0) vacc[4 * (size_t)gid] = make_float4(pad[0], pad[1], pad[2], pad[3]);
-    if (s == 1) vacc[4 * (size_t)gid + 1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
-    if (s == 2) vacc[4 * (size_t)gid + 2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
+    if (r == 0) vacc[4 * (size_t)gid] = make_float4(pad[0], pad[1], pad[2], pad[3]);
+    if (r == 1) vacc[4 * (size_t)gid + 1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
+    if (r == 2) vacc[4 * (size_t)gid + 2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
   }
-}
-
-
-// ---------------------------------------------------------------------------------------------------
-// "Slab" backward for small splats (every r_cull < BX/2 px, BX = 4 or 8: the alpha >= 1/255 disc spans at most
-// BX pixel centres per axis).  Hardware ablation of k_fraster_bwd (profiles/r02_backward_ablation.txt): its
-// atomics cost nothing, its 64-lane reduce-scatter costs 38 % and its wave-wide walk (18 % of the lanes hold a
-// pixel the splat reaches) the rest.  Here nothing is reduced across a wave and no float atomic touches LDS:
-//   phase 1 (lane = pixel, the per-pixel walk of k_praster_fwd run back to front): per composited
-//            (pixel, splat) the lane stores  (w, f) = (vis * v_alpha [0 when alpha is clamped], alpha * T [* v_depth
-//            when only the depth channel carries a gradient])  into the splat's own BX x BX slab in LDS and
-//            raises the slot's byte in a validity map (plain byte stores, no atomics);
-//   phase 2 (BX lanes = one splat, one lane per slab row): the lane walks the raised bytes of its row, rebuilds
-//            dx, dy from the splat's own record and sums v_xy, v_conic, v_opacity, v_colour; log2(BX) DPP steps
-//            fold the rows; the (tile, splat) total leaves as one packed row of global atomics.
-// The batch is B = 64 (BX = 8) or 256 (BX = 4) list entries so that the slabs take 32 KB.
-// ---------------------------------------------------------------------------------------------------
-template <int D, int CG, int BX>
-struct SStage {
-  static constexpr bool RGBS = (D >= 3) && (CG == D);
-  static constexpr int B = (BX == 4) ? 256 : 64;
-  static constexpr int NS = BX * BX;
-  float4 s0[B];
-  float4 s1[B];
-  float4 s2[RGBS ? B : 1];
-  int32_t id[B];
-  int32_t org[B];            // box origin (first pixel column | first pixel row << 16), image pixels, biased by 4096
-  uint16_t qlist[4][B];
-  int qcnt[4][4];
-  float2 slab[B * NS];
-  unsigned char valid[B * NS];
-  float vcs[(CG == D && D > 1) ? 256 * D : 1];  // upstream colour gradients per tile pixel (all-channel variant)
-};
-
-template <typename Stage, int B>
-__device__ __forceinline__ int compact_quadrants_n(Stage& sb, int tid, bool valid_rec, float x, float y, float r,
-                                                   float tile_x0, float tile_y0) {
-  // compact_quadrants for a batch of B <= 256 records staged by threads 0..B-1 (waves without records vote 0)
-  int lane = tid & 63, wv = tid >> 6;
-  unsigned long long Bm[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float cx = tile_x0 + 4.f + 8.f * (float)(q & 1), cy = tile_y0 + 4.f + 8.f * (float)(q >> 1);
-    Bm[q] = __ballot(valid_rec && (fabsf(x - cx) <= r + 3.5f) && (fabsf(y - cy) <= r + 3.5f));
-  }
-  if (lane < 4) {
-    unsigned long long b = lane == 0 ? Bm[0] : (lane == 1 ? Bm[1] : (lane == 2 ? Bm[2] : Bm[3]));
-    sb.qcnt[wv][lane] = __popcll(b);
-  }
-  __syncthreads();
-  unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if ((Bm[q] >> lane) & 1ull) {
-      int base = 0;
-      for (int w = 0; w < wv; ++w) base += sb.qcnt[w][q];
-      sb.qlist[q][base + __popcll(Bm[q] & lt)] = (uint16_t)tid;
-    }
-  }
-  __syncthreads();
-  return sb.qcnt[0][wv] + sb.qcnt[1][wv] + sb.qcnt[2][wv] + sb.qcnt[3][wv];
-}
-
-template <int D, int CG, int BX>
-__device__ __forceinline__ void sraster_bwd_body(
-    SStage<D, CG, BX>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
-    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, int32_t* __restrict__ flags, long long rs,
-    long long re, int tid, int txi, int tyi, int qx, int qy, int i, int j, float px, float py, bool inside,
-    int bin_final, int wave_final, float T_final, const float (&vc)[D], float va) {
-  constexpr bool RGB = D >= 3;
-  constexpr bool DEPTH = (D == 1) || (D == 4);
-  constexpr bool RGBS = SStage<D, CG, BX>::RGBS;
-  constexpr int B = SStage<D, CG, BX>::B;
-  constexpr int NS = BX * BX;
-  constexpr int A = 6 + D;  // gradient row: [v_xy 2][v_conic 3][v_opacity 1][v_colour D]
-  int lane = tid & 63, wv = tid >> 6;
-  float T = T_final;
-  float Bp = -T_final * va;  // running  sum_behind(fac * cdot) - T_final * v_A   (see fused.hip)
-  if (CG == D && D > 1) {
-    int pl = (i - tyi * 16) * 16 + (j - txi * 16);
-#pragma unroll
-    for (int k = 0; k < D; ++k) sb.vcs[pl * D + k] = vc[k];
-  }
-  int nb = (int)((re - rs + B - 1) / B);
-  bool miss = false;
-  for (int b = 0; b < nb; ++b) {
-    long long bend = re - 1 - (long long)b * B;  // slot t <-> absolute index bend - t (back to front)
-    int bsize = (int)min((long long)B, bend + 1 - rs);
-    __syncthreads();  // phase 2 of the previous batch is done with the records and the slabs
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
-    if (tid < bsize) {
-      int g = flatten_ids[bend - tid];
-      sb.id[tid] = g;
-      r0 = GSL_Q(Q0, g);
-      r1 = GSL_Q(Q1, g);
-      sb.s0[tid] = r0;
-      sb.s1[tid] = r1;
-      if (RGBS) sb.s2[tid] = GSL_Q(Q2, g);
-      sb.org[tid] = (tiny_origin(r0.x, r1.w) + 4096) | ((tiny_origin(r0.y, r1.w) + 4096) << 16);
-    }
-    {
-      uint4* vz = reinterpret_cast<uint4*>(sb.valid);
-      for (int k = tid; k < B * NS / 16; k += 256) vz[k] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    int n = compact_quadrants_n<SStage<D, CG, BX>, B>(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16),
-                                                      (float)(tyi * 16));
-    // ---- phase 1: lane = pixel.  Slots below t_first hold splats behind everything this quadrant composited.
-    int t_first = (int)max((long long)0, bend - (long long)wave_final);
-    int t_lane = inside ? (int)max((long long)0, bend - (long long)bin_final) : 1 << 30;  // first slot of this pixel
-    for (int c = 0; c < n; c += 64) {
-      int e = c + lane;
-      int lox = 1, hix = 0, loy = 1, hiy = 0;
-      if (e < n) {
-        int t = sb.qlist[wv][e];
-        if (t >= t_first) {
-          float4 a0 = sb.s0[t];
-          float r = sb.s1[t].w;
-          box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
-          box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
-        }
-      }
-      unsigned mlo, mhi;
-      pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        unsigned m = half ? mhi : mlo;
-        while (__ballot(m != 0)) {
-          if (m != 0) {
-            int bit = __ffs((int)m) - 1;
-            m &= m - 1;
-            int t = sb.qlist[wv][c + half * 32 + bit];
-            if (t >= t_lane) {
-              float4 q0 = sb.s0[t], q1 = sb.s1[t];
-              float dx = q0.x - px, dy = q0.y - py;
-              float gx = q1.x * dx + q1.y * dy;
-              float gy = q1.y * dx + q1.z * dy;
-              float sigma = 0.5f * (dx * gx + dy * gy);
-              float vis = __expf(-sigma);
-              float opv = q0.w * vis;
-              float alpha = fminf(GSL_ALPHA_MAX, opv);
-              if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
-                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-                T *= ra;
-                float fac = alpha * T;
-                float cdot;
-                if (CG == D) {
-                  cdot = 0.f;
-                  if (RGB) {
-                    float4 q2 = sb.s2[t];
-                    cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
-                  }
-                  if (DEPTH) cdot += q0.z * vc[D - 1];
-                } else {
-                  cdot = q0.z * vc[D - 1];
-                }
-                float v_alpha = T * cdot - ra * Bp;
-                Bp += fac * cdot;
-                float w = (opv <= GSL_ALPHA_MAX) ? vis * v_alpha : 0.f;  // alpha clamped => no geometric gradient
-                int og = sb.org[t];
-                int cc = j - ((og & 0xFFFF) - 4096), rr = i - ((og >> 16) - 4096);
-                if ((unsigned)cc < (unsigned)BX && (unsigned)rr < (unsigned)BX) {
-                  int slot = t * NS + rr * BX + cc;
-                  sb.slab[slot] = make_float2(w, (CG == D && D > 1) ? fac : fac * vc[D - 1]);
-                  sb.valid[slot] = 1;
-                } else {
-                  miss = true;  // the splat is larger than the slab: reported, never silently dropped
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // ---- phase 2: BX lanes = one splat (lane = slab row)
-#pragma unroll 1
-    for (int item = tid; item < B * BX; item += 256) {
-      int s = item / BX, rr = item % BX;
-      float acc[A];
-#pragma unroll
-      for (int k = 0; k < A; ++k) acc[k] = 0.f;
-      unsigned long long vb = 0;
-      if (s < bsize) {
-        if (BX == 8) vb = *reinterpret_cast<const unsigned long long*>(&sb.valid[s * NS + rr * 8]);
-        else vb = *reinterpret_cast<const unsigned*>(&sb.valid[s * NS + rr * 4]);
-      }
-      if (vb) {
-        float4 q0 = sb.s0[s], q1 = sb.s1[s];
-        int og = sb.org[s];
-        int ox = (og & 0xFFFF) - 4096, oy = (og >> 16) - 4096;
-        float dy = q0.y - ((float)(oy + rr) + 0.5f);
-        while (vb) {
-          int k = (__ffsll((long long)vb) - 1) >> 3;
-          vb &= vb - 1;
-          float2 wf = sb.slab[s * NS + rr * BX + k];
-          float dx = q0.x - ((float)(ox + k) + 0.5f);
-          float gx = q1.x * dx + q1.y * dy;
-          float gy = q1.y * dx + q1.z * dy;
-          float v_sigma = -q0.w * wf.x;
-          float hs = 0.5f * v_sigma;
-          acc[0] += v_sigma * gx;
-          acc[1] += v_sigma * gy;
-          acc[2] += hs * dx * dx;
-          acc[3] += v_sigma * dx * dy;
-          acc[4] += hs * dy * dy;
-          acc[5] += wf.x;
-          if (CG == D && D > 1) {
-            int pl = (oy + rr - tyi * 16) * 16 + (ox + k - txi * 16);
-#pragma unroll
-            for (int ch = 0; ch < D; ++ch) acc[6 + ch] += wf.y * sb.vcs[pl * D + ch];
-          } else {
-            acc[6 + D - 1] += wf.y;
-          }
-        }
-      }
-      // fold the BX rows of the splat (quad steps, then the half-row mirror for BX = 8)
-      bool nz = false;
-#pragma unroll
-      for (int k = 0; k < A; ++k) {
-        float v = acc[k];
-        v += dpp_get<0xB1>(v);                 // quad_perm [1,0,3,2]
-        v += dpp_get<0x4E>(v);                 // quad_perm [2,3,0,1]
-        if (BX == 8) v += dpp_get<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of each 8 lanes
-        acc[k] = v;
-        nz = nz || (v != 0.f);
-      }
-      if (nz && s < bsize) {
-        size_t g = (size_t)sb.id[s];
-        // lane rr adds row entries rr, rr + BX, ...: BX consecutive floats per splat and instruction
-#pragma unroll
-        for (int k0 = 0; k0 < A; k0 += BX) {
-          float v = 0.f;
-#pragma unroll
-          for (int u = 0; u < BX; ++u)
-            if (k0 + u < A && rr == u) v = acc[k0 + u];
-          if (k0 + rr < A && v != 0.f) atomicAdd(&vacc[g * 16 + k0 + rr], v);
-        }
-      }
-    }
-  }
-  if (miss && flags) flags[0] = 1;  // sticky: some (pixel, splat) fell outside its slab (r_cull >= BX/2)
-}
-
-template <int D, bool ED, int BX>
-__global__ __launch_bounds__(256) void k_sraster_bwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
-    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc, int32_t* __restrict__ flags) {
-  constexpr size_t SZ_ALL = sizeof(SStage<D, D, BX>), SZ_ONE = sizeof(SStage<D, 1, BX>);
-  __shared__ __attribute__((aligned(16))) unsigned char sraw[SZ_ALL > SZ_ONE ? SZ_ALL : SZ_ONE];
-  __shared__ int s_final[4];
-  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
-  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  int j = qx + (lane & 7), i = qy + (lane >> 3);
-  float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W);
-
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs >= re) return;
-
-  size_t pid = inside ? ((size_t)i * W + j) : 0;
-  float Aimg = inside ? alphas[pid] : 0.f;
-  float T_final = 1.f - Aimg;
-  int bin_final = inside ? last_ids[pid] : -1;
-  float vc[D];
-  float va = inside ? v_alphas[pid] : 0.f;
-#pragma unroll
-  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
-  if (ED && inside) {
-    float dn = render[pid * D + (D - 1)];
-    float vd = vc[D - 1];
-    if (Aimg >= 1e-10f) va += -vd * dn / Aimg;
-    vc[D - 1] = vd / fmaxf(Aimg, 1e-10f);
-  }
-  int wave_final = bin_final;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
-  if (lane == 0) s_final[wv] = wave_final;
-  bool rgb_grad = false;
-  if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
-  int any_rgb = __syncthreads_or(rgb_grad);
-  int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
-  if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
-  if (rs >= re) return;
-  if (D == 4 && !any_rgb)
-    sraster_bwd_body<D, 1, BX>(*reinterpret_cast<SStage<D, 1, BX>*>(sraw), Q0, Q1, Q2, flatten_ids, vacc, flags, rs, re,
-                               tid, txi, tyi, qx, qy, i, j, px, py, inside, bin_final, wave_final, T_final, vc, va);
-  else
-    sraster_bwd_body<D, D, BX>(*reinterpret_cast<SStage<D, D, BX>*>(sraw), Q0, Q1, Q2, flatten_ids, vacc, flags, rs, re,
-                               tid, txi, tyi, qx, qy, i, j, px, py, inside, bin_final, wave_final, T_final, vc, va);
 }
 
 }  // namespace gsl
-
-// Slab backward (every r_cull < box/2, box = 4 or 8).  `flags` (int32[>=1], may be NULL): flags[0] is set to 1 when a
-// (pixel, splat) pair fell outside its slab, i.e. the precondition did not hold -- the caller polls it.
-extern "C" int gsl_slab_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int box,
-                                   int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                                   const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                                   const float* render, const float* alphas, const int32_t* last_ids,
-                                   const float* v_render, const float* v_alphas, float* vacc, int32_t* flags,
-                                   void* stream) {
-  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0 || (box != 4 && box != 8))
-    return GSL_ERR_BAD_ARG;
-  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
-  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
-  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
-  if (capacity == 0 || ty0 == ty1) return GSL_OK;
-  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  int nblk = (ty1 - ty0) * tile_w;
-#define CALL_SB(DD, EE)                                                                                          \
-  do {                                                                                                           \
-    if (box == 4)                                                                                                \
-      hipLaunchKernelGGL((gsl::k_sraster_bwd<DD, EE, 4>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,       \
-                         (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                         flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,    \
-                         flags);                                                                                  \
-    else                                                                                                         \
-      hipLaunchKernelGGL((gsl::k_sraster_bwd<DD, EE, 8>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,       \
-                         (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                         flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,    \
-                         flags);                                                                                  \
-  } while (0)
-  if (channels == 1) { if (ed) CALL_SB(1, true); else CALL_SB(1, false); }
-  else if (channels == 3) { CALL_SB(3, false); }
-  else if (channels == 4) { if (ed) CALL_SB(4, true); else CALL_SB(4, false); }
-  else return GSL_ERR_BAD_ARG;
-#undef CALL_SB
-  GSL_CHECK_LAUNCH();
-  return GSL_OK;
-}
 
 extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                    int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                    const int32_t* flatten_ids, int64_t capacity, const float* render,
                                    const float* alphas, const int32_t* last_ids, const float* v_render,
-                                   const float* v_alphas, float* trec, float* vcT, void* stream) {
+                                   const float* v_alphas, float* trec, float* vcT, int row0, int row1,
+                                   int32_t* flags, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0)
+      capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
   if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas || !trec || !vcT)
@@ -1042,7 +462,7 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
   hipLaunchKernelGGL((gsl::k_tiny_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,            \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas,         \
-                     (float2*)trec, vcT)
+                     (float2*)trec, vcT, row0, row1, flags)
   if (channels == 1) { if (ed) CALL_TB(1, true); else CALL_TB(1, false); }
   else if (channels == 3) { CALL_TB(3, false); }
   else if (channels == 4) { if (ed) CALL_TB(4, true); else CALL_TB(4, false); }
@@ -1059,18 +479,15 @@ extern "C" int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* 
   if (N == 0) return GSL_OK;
   if (!Q0 || !Q1 || !radii || !trec || !vcT || !vacc) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  unsigned grid = (unsigned)(((size_t)N * 16 + 255) / 256);
+  unsigned grid = (unsigned)(((size_t)N * 4 + 255) / 256);
 #define CALL_TG(DD)                                                                                              \
   hipLaunchKernelGGL((gsl::k_tiny_gather<DD>), dim3(grid), dim3(256), 0, st, (const float4*)Q0, (const float4*)Q1, \
-                     radii, N, width, height, (float2*)trec, vcT, (float4*)vacc)
+                     radii, N, width, height, (float4*)trec, vcT, (float4*)vacc)
   if (channels == 1) CALL_TG(1); else if (channels == 3) CALL_TG(3); else CALL_TG(4);
 #undef CALL_TG
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
-
-namespace gsl {
-}  // namespace gsl
 
 #define GSL_P_DISPATCH(D, ED, CALL)                                \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }      \
@@ -1078,12 +495,13 @@ namespace gsl {
   else if (D == 4) { if (ED) CALL(4, true); else CALL(4, false); } \
   else return GSL_ERR_BAD_ARG;
 
-extern "C" int gsl_px_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+// Compositing forward (k_praster_fwd).  Pixel rows outside [row0, row1) are not touched.
+extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
-                                 int32_t* last_ids, void* stream) {
+                                 int32_t* last_ids, int row0, int row1, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0)
+      capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
   if (!tile_offsets || !render || !alphas || !last_ids) return GSL_ERR_BAD_ARG;
@@ -1096,34 +514,9 @@ extern "C" int gsl_px_raster_fwd(const float* Q0, const float* Q1, const float* 
 #define CALL_PF(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids)
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
-  GSL_CHECK_LAUNCH();
-  return GSL_OK;
-}
-
-extern "C" int gsl_px_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
-                                 int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
-                                 const int32_t* flatten_ids, int64_t capacity, const float* render,
-                                 const float* alphas, const int32_t* last_ids, const float* v_render,
-                                 const float* v_alphas, float* vacc, void* stream) {
-  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
-      capacity < 0)
-    return GSL_ERR_BAD_ARG;
-  if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
-  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
-  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
-  if (capacity == 0 || ty0 == ty1) return GSL_OK;
-  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  int nblk = (ty1 - ty0) * tile_w;
-#define CALL_PB(DD, EE)                                                                                       \
-  hipLaunchKernelGGL((gsl::k_praster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
-                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc)
-  GSL_P_DISPATCH(channels, ed, CALL_PB)
-#undef CALL_PB
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -283,7 +283,34 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   write_pose(q, t, c2w, viewmat);
 }
 
+// The 16 floats one rank contributes to the per-iteration all-reduce: 12 pose-gradient entries (rows 0..2 of
+// d loss / d viewmat) and its two loss sums (fixed-order sum of its block partials); entries 14, 15 are zero.
+__global__ __launch_bounds__(256) void k_pack_pose_reduce(const float* __restrict__ v_viewmat,
+                                                          const float* __restrict__ partial, int nb,
+                                                          float* __restrict__ out16) {
+  __shared__ float red[4][2];
+  float a0 = 0.f, a1 = 0.f;
+  for (int b = threadIdx.x; b < nb; b += 256) { a0 += partial[2 * (size_t)b]; a1 += partial[2 * (size_t)b + 1]; }
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float s0 = wave_sum(a0), s1 = wave_sum(a1);
+  if (lane == 0) { red[wv][0] = s0; red[wv][1] = s1; }
+  __syncthreads();
+  if (threadIdx.x < 12) out16[threadIdx.x] = v_viewmat[threadIdx.x];
+  else if (threadIdx.x < 14)
+    out16[threadIdx.x] = red[0][threadIdx.x - 12] + red[1][threadIdx.x - 12] + red[2][threadIdx.x - 12] + red[3][threadIdx.x - 12];
+  else if (threadIdx.x < 16) out16[threadIdx.x] = 0.f;
+}
+
 }  // namespace gsl
+
+extern "C" int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials, float* out16,
+                                    void* stream) {
+  if (!v_viewmat || !out16 || n_partials < 0 || (n_partials > 0 && !loss_partials)) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_pack_pose_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, v_viewmat, loss_partials,
+                     n_partials, out16);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
 
 extern "C" size_t gsl_loss_ws_bytes(int width, int height) {
   size_t P = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);

@@ -22,37 +22,17 @@ MAX_STRIP_TILES = 8192
 _MODES = {"RGB": (3, False), "D": (1, False), "ED": (1, True), "RGB+D": (4, False), "RGB+ED": (4, True)}
 
 
-def _raster_fn(lib, which: str):
-    """Compositing kernels.  "px" = every lane walks its own pixel's candidate mask (csrc/raster_px.hip),
-    "quad" = the wave walks the list together with ballot culling and a wave reduce-scatter
-    (csrc/fused.hip).  Measured on MI355X (1 M splats, 1200x680): forward px 103-185 us vs quad
-    122-210 us; backward quad 306-475 us vs px 472-1185 us (ds_add_f32 issues at ~80 ns per
-    wave-instruction per CU, 45x slower than ds_add_u32), hence the defaults.
-    GSLOC_RASTER_FWD / GSLOC_RASTER_BWD override."""
-    import os
-    kind = os.environ.get("GSLOC_RASTER_" + which.upper(), "px" if which == "fwd" else "mfma")
-    assert kind in ("px", "quad", "mfma"), kind
-    if kind == "mfma":  # quad walk, per-splat pixel sums on the matrix cores (backward only)
-        assert which == "bwd"
-        return lib.gsl_mfma_raster_bwd
-    return getattr(lib, ("gsl_px_raster_" if kind == "px" else "gsl_fused_raster_") + which)
-
-
 def tile_n_bits(n_tiles: int) -> int:
     return int(math.floor(math.log2(n_tiles))) + 1
 
 
 def alloc_records(lib, N: int, rgb: bool, dev, zero: bool = False):
-    """The per-Gaussian record arrays Q0, Q1, Q2 ([N,4] each; Q2 None without colours) in the layout the loaded
-    library expects (gsl_record_stride): three separate arrays, or columns of one [N,16] array of 64-byte rows."""
+    """The per-Gaussian record arrays Q0, Q1, Q2 ([N,4] each; Q2 None without colours)."""
     make = torch.zeros if zero else torch.empty
-    if lib.gsl_record_stride() == 1:
-        Q0 = make(N, 4, dtype=torch.float32, device=dev)
-        Q1 = make(N, 4, dtype=torch.float32, device=dev)
-        Q2 = make(N, 4, dtype=torch.float32, device=dev) if rgb else None
-        return Q0, Q1, Q2
-    rows = make(N, 16, dtype=torch.float32, device=dev)
-    return rows[:, 0:4], rows[:, 4:8], (rows[:, 8:12] if rgb else None)
+    Q0 = make(N, 4, dtype=torch.float32, device=dev)
+    Q1 = make(N, 4, dtype=torch.float32, device=dev)
+    Q2 = make(N, 4, dtype=torch.float32, device=dev) if rgb else None
+    return Q0, Q1, Q2
 
 
 class _FusedRasterization(torch.autograd.Function):
@@ -96,9 +76,9 @@ class _FusedRasterization(torch.autograd.Function):
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, 1, dtype=f32, device=dev)
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
-        check(_raster_fn(lib, 'fwd')(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
+        check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
-                                       ptr(last_ids), st), "gsl_fused_raster_fwd")
+                                       ptr(last_ids), 0, H, st), "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
                               comps if antialiased else torch.empty(0, device=dev), offs, flatten_ids, render,
@@ -131,10 +111,10 @@ class _FusedRasterization(torch.autograd.Function):
         v_alphas = v_alphas.contiguous()
         vacc = torch.zeros(N, 16, dtype=f32, device=dev)
         n_isects = ctx.n_isects
-        check(_raster_fn(lib, 'bwd')(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
+        check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(vacc), st), "gsl_fused_raster_bwd")
+                                       ptr(vacc), 0, H, st), "gsl_fused_raster_bwd")
         ni = ctx.needs_input_grad
         full = any(ni[:5])
         v_means = v_quats = v_scales = v_opac = v_colors = None

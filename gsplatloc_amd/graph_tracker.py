@@ -8,9 +8,16 @@ decay and the early-stop bookkeeping (data/base.py:34-43) live in three device k
 synchronisation, replayed as a HIP graph.  The host looks at the device-side "stopped" flag every
 ``poll`` iterations only.
 
-Several GPUs (``rows=``, ``group=``): every rank tracks the same pose on its tile-row strip (plus one halo
-tile row), the 12 pose-gradient entries and the two loss sums are summed with ONE all-reduce of 16 floats
-per iteration, and every rank applies the identical update.
+Several GPUs (``rows=``, ``group=``): every rank tracks the same pose on its tile-row strip (plus ONE pixel row
+of halo on each interior side), the 12 pose-gradient entries and the two loss sums are packed by a kernel of the
+library into one 16-float buffer, summed with ONE all-reduce per iteration, and every rank applies the identical
+update.  The iteration is then two graph-replayable halves around the collective: [render, loss, backward, pack]
+and [pose step].
+
+Overflow handling: the kernels never drop work silently.  A splat that outgrows the tiny-splat backward raises a
+sticky device flag, and the intersection count is compared with the buffer capacity; both are read at the
+existing poll of the "stopped" flag, and on either the frame is re-run from its initial pose with the general
+backward / a larger capacity.
 """
 from __future__ import annotations
 
@@ -24,7 +31,7 @@ from ._lib import check, current_stream, load_library, ptr
 from .context import RenderContext
 from .my_gsplat.trainer import TrackerConfig, TrackResult
 from .my_gsplat.utils import rgb_to_sh
-from .parallel import halo_rows
+from .parallel import halo_pixel_rows, halo_rows
 
 
 class GraphTracker:
@@ -43,12 +50,13 @@ class GraphTracker:
         th = (self.H + 15) // 16
         self.rows = rows if rows is not None else (0, th)
         self.render_rows = halo_rows(self.rows, th) if rows is not None else (0, th)
+        self.pixel_rows = halo_pixel_rows(self.rows, self.H) if rows is not None else (0, self.H)
         self.row0, self.row1 = self.rows[0] * 16, min(self.rows[1] * 16, self.H)
         sh_deg = config.gs.sh_degree
         self.K_sh = (sh_deg + 1) ** 2
         self.rc = RenderContext(self.N, self.W, self.H, render_mode, sh_degree=sh_deg, K_sh=self.K_sh, device=self.dev,
                                 near_plane=config.gs.near_plane, far_plane=config.gs.far_plane,
-                                tile_rows=self.render_rows, full_grads=False)
+                                tile_rows=self.render_rows, pixel_rows=self.pixel_rows, full_grads=False)
         f32 = torch.float32
         d = self.dev
         self.means = torch.zeros(self.N, 3, dtype=f32, device=d)
@@ -72,8 +80,10 @@ class GraphTracker:
         self.partials = torch.zeros(max(self.n_partials, 1) * 2, dtype=f32, device=d)
         self.loss_hist = torch.zeros(max(config.max_steps, 1), dtype=f32, device=d)
         self.reduce_buf = torch.zeros(16, dtype=f32, device=d)  # 12 pose-gradient entries + 2 loss sums
-        self.graph = None
+        self._host16 = None
+        self.graph = self.graph_tail = None
         self._side = torch.cuda.Stream(device=d)
+        self.headroom = 1.5
 
     # ------------------------------------------------------------------ frame setup
     def load_frame(self, tar_points: Tensor, colors: Tensor, scales: Tensor, src_depth: Tensor, tar_c2w: Tensor,
@@ -96,11 +106,14 @@ class GraphTracker:
         cam = self.cfg.camera
         check(self.lib.gsl_pose_init(ptr(self.pose_f), ptr(self.pose_i), ptr(self.init_c2w), cam.quat_lr, cam.trans_lr,
                                      ptr(self.c2w), ptr(self.viewmat), current_stream()), "gsl_pose_init")
-        self.rc.calibrate(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K, headroom=1.5)
-        self.graph = None  # capacity buffers may have been reallocated
+        self.rc.calibrate(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K,
+                          headroom=self.headroom)
+        self.graph = self.graph_tail = None  # capacity buffers may have been reallocated
 
     # ------------------------------------------------------------------ one iteration
-    def _iteration(self) -> None:
+    def _render_and_loss(self) -> None:
+        """Forward, loss, backward; with several ranks also the pack of this rank's 16 floats.  Library launches
+        and memsets only: safe to capture."""
         cfg, lib = self.cfg, self.lib
         st = current_stream()
         self.rc.forward(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K)
@@ -108,55 +121,116 @@ class GraphTracker:
         check(lib.gsl_tracking_loss(ptr(self.rc.render), self.rc.D, ptr(self.gt_depth), self.W, self.H, self.row0,
                                     self.row1, cfg.depth_lambda, edge_w, ptr(self.v_render), ptr(self.partials), None,
                                     ptr(self.loss_ws), self.loss_ws_bytes, st), "gsl_tracking_loss")
-        g = self.rc.backward(self.v_render, self.v_alphas, full=False)
-        loss_sums = None
-        v_viewmat = g["viewmat"]
+        self.rc.backward(self.v_render, self.v_alphas, full=False)
         if self.group is not None:
-            import torch.distributed as dist
-            self.reduce_buf[:12].copy_(v_viewmat.reshape(16)[:12])
-            self.reduce_buf[12:14].copy_(self.partials.view(-1, 2).sum(0))
-            dist.all_reduce(self.reduce_buf, group=self.group)  # THE collective: 16 floats
-            v_viewmat = self.reduce_buf
-            loss_sums = self.reduce_buf[12:14]
+            check(lib.gsl_pack_pose_reduce(ptr(self.rc.v_viewmat), ptr(self.partials), self.n_partials,
+                                           ptr(self.reduce_buf), st), "gsl_pack_pose_reduce")
+
+    def _pose_step(self) -> None:
+        cfg, lib = self.cfg, self.lib
+        if self.group is not None:  # summed over the ranks: gradient in [0,12), loss sums in [12,14)
+            v_viewmat, loss_sums = ptr(self.reduce_buf), self.reduce_buf.data_ptr() + 12 * 4
+        else:
+            v_viewmat, loss_sums = ptr(self.rc.v_viewmat), None
         cam = cfg.camera
+        edge_w = 1.0 - cfg.depth_lambda - cfg.normal_lambda
         gamma = 0.2 ** (1.0 / cfg.max_steps)
-        check(lib.gsl_pose_step(ptr(self.pose_f), ptr(self.pose_i), ptr(v_viewmat), ptr(self.partials),
-                                self.n_partials, ptr(loss_sums), ptr(self.gt_c2w), self.W, self.H, cfg.depth_lambda,
+        check(lib.gsl_pose_step(ptr(self.pose_f), ptr(self.pose_i), v_viewmat, ptr(self.partials),
+                                self.n_partials, loss_sums, ptr(self.gt_c2w), self.W, self.H, cfg.depth_lambda,
                                 edge_w, 0.9, 0.999, 1e-8, cam.quat_opt_reg, cam.trans_opt_reg, gamma, cfg.min_step,
                                 cfg.patience, int(cfg.early_stop), cfg.max_steps, ptr(self.c2w), ptr(self.viewmat),
-                                ptr(self.loss_hist), st), "gsl_pose_step")
+                                ptr(self.loss_hist), current_stream()), "gsl_pose_step")
+
+    def _collective(self) -> None:
+        """THE collective of the path: 16 floats summed over the ranks (RCCL on device buffers; the one-GPU
+        rehearsal's gloo group goes through a pinned host buffer)."""
+        import torch.distributed as dist
+        if not self.reduce_buf.is_cuda:  # host tensors (CPU tests of the glue)
+            dist.all_reduce(self.reduce_buf, group=self.group)
+        elif dist.get_backend(self.group) == "gloo":
+            if self._host16 is None:
+                self._host16 = torch.zeros(16, dtype=torch.float32).pin_memory()
+            self._host16.copy_(self.reduce_buf, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            dist.all_reduce(self._host16, group=self.group)
+            self.reduce_buf.copy_(self._host16, non_blocking=True)
+        else:
+            dist.all_reduce(self.reduce_buf, group=self.group)
+
+    def _iteration(self) -> None:
+        if self.group is None:
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._render_and_loss()
+                self._pose_step()
+            return
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._render_and_loss()
+        self._collective()
+        if self.graph_tail is not None:
+            self.graph_tail.replay()
+        else:
+            self._pose_step()
+
+    def _state(self):
+        return (self.pose_f, self.pose_i, self.c2w, self.viewmat, self.loss_hist)
 
     def _capture(self) -> None:
-        state = (self.pose_f.clone(), self.pose_i.clone(), self.c2w.clone(), self.viewmat.clone(), self.loss_hist.clone())
+        """One HIP graph per iteration (one rank), or one per half around the collective (several ranks)."""
+        state = [t.clone() for t in self._state()]
         with torch.cuda.stream(self._side):
-            self._iteration()  # warm-up outside capture
+            self._render_and_loss()  # warm-up outside capture
+            self._pose_step()
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self._side):
-                self._iteration()
+                self._render_and_loss()
+                if self.group is None:
+                    self._pose_step()
+            if self.group is not None:
+                self.graph_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_tail, stream=self._side):
+                    self._pose_step()
         torch.cuda.synchronize()
-        # restore the optimiser state consumed by the warm-up and by capture
-        for dst, src in zip((self.pose_f, self.pose_i, self.c2w, self.viewmat, self.loss_hist), state):
+        for dst, src in zip(self._state(), state):  # restore what the warm-up and the captures consumed
             dst.copy_(src)
 
     # ------------------------------------------------------------------ frame loop
     def run(self) -> TrackResult:
         """Optimise the loaded frame until early stop or max_steps.  Returns the reference's read-outs."""
-        use_graph = self.use_graph and self.group is None
-        if use_graph and self.graph is None:
-            self._capture()
-        done = 0
-        while done < self.cfg.max_steps:
-            n = min(self.poll, self.cfg.max_steps - done)
-            for _ in range(n):
-                if use_graph:
-                    self.graph.replay()
-                else:
+        start = [t.clone() for t in self._state()]
+        for attempt in range(4):
+            if self.use_graph and self.graph is None:
+                self._capture()
+            done, redo = 0, False
+            while done < self.cfg.max_steps:
+                n = min(self.poll, self.cfg.max_steps - done)
+                for _ in range(n):
                     self._iteration()
-            done += n
-            if int(self.pose_i[2].item()):  # stopped (early stop or max_steps) -- the only host sync
+                done += n
+                # the only host sync: stopped flag, intersection count, tiny-backward overflow flag
+                stopped, n_is, tiny_over = int(self.pose_i[2].item()), int(self.rc.n_is.item()), self.rc.tiny_overflowed()
+                if n_is > self.rc.capacity or tiny_over:
+                    redo = True
+                    break
+                if stopped:
+                    break
+            if not redo:
                 break
-        self.rc.check_capacity()
+            # recover: iterations since the last poll ran on truncated lists or a dropped gradient
+            if tiny_over:
+                self.rc.use_general_backward()
+            if n_is > self.rc.capacity:
+                self.headroom *= 1.5
+                self.rc._alloc_isects(int(n_is * self.headroom) + 1024)
+            self.graph = self.graph_tail = None
+            for dst, src in zip(self._state(), start):
+                dst.copy_(src)
+        else:
+            raise RuntimeError("the frame kept overflowing its buffers after three recalibrations")
         pi = self.pose_i.tolist()
         pf = self.pose_f.tolist()
         res = TrackResult()

@@ -62,9 +62,17 @@ def all_reduce_pose(buf16: Tensor, group=None) -> Tensor:
 
 
 def halo_rows(rows: Tuple[int, int], tile_h: int) -> Tuple[int, int]:
-    """Tile rows a rank must render so that the 3x3 Sobel of its own pixel rows is exact: its strip
-    plus one tile row on each interior side."""
+    """Tile rows a rank must BIN so that the 3x3 Sobel of its own pixel rows is exact: its strip plus the tile
+    row that holds the one halo pixel row on each interior side.  Only that pixel row of the extra tile row is
+    composited (see halo_pixel_rows)."""
     return max(rows[0] - 1, 0), min(rows[1] + 1, tile_h)
+
+
+def halo_pixel_rows(rows: Tuple[int, int], height: int, tile_size: int = 16) -> Tuple[int, int]:
+    """Pixel rows a rank composites and back-propagates: its own rows plus ONE pixel row of halo on each interior
+    side (the support of the 3x3 Sobel, /root/reference/src/my_gsplat/loss.py:51-52)."""
+    r0, r1 = rows[0] * tile_size, min(rows[1] * tile_size, height)
+    return max(r0 - 1, 0), min(r1 + 1, height)
 
 
 def strip_tracking_loss(depths: Tensor, depths_gt: Tensor, rows: Tuple[int, int], height: int,

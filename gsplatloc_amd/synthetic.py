@@ -93,3 +93,35 @@ def frame_pair(W: int = 160, H: int = 120, rot_deg: float = 0.5, trans: float = 
     g = torch.Generator().manual_seed(seed)
     rgb = torch.rand(H * W, 3, generator=g)
     return dict(K=K, W=W, H=H, depth0=d0, depth1=d1, c2w0=c2w0, c2w1=c2w1, rgb=rgb)
+
+
+def depth_frame_scene(W: int = 640, H: int = 480, stride: int = 1, holes: bool = False, device="cuda", seed: int = 3,
+                      hole_frac: float = 0.08) -> Dict:
+    """Workloads S / T of SURVEY.md 8(d): the Gaussians GsplatLoc builds from one depth frame
+    (/root/reference/src/data/Image.py:29-35, my_gsplat/geometry.py:44-66,138-161): every ``stride``-th pixel of a
+    synthetic room depth image back-projected in raster order, isotropic scales from the 4 nearest neighbours as the
+    reference codes them (device k-NN), opacity 1, SH degree 1 with a random DC colour.  ``holes`` zeroes rectangular
+    patches of the depth image as a TUM frame has them: those points sit at the camera origin and are culled by the
+    near plane.  Rendered from the frame pair's second pose.  Needs the GPU (k-NN kernels)."""
+    from .my_gsplat.geometry import depth_to_points, init_gs_scales
+
+    fp = frame_pair(W, H, rot_deg=0.4, trans=0.015, seed=seed)
+    depth = fp["depth0"].clone()
+    if holes:
+        g = torch.Generator().manual_seed(seed)
+        for _ in range(int(hole_frac * W * H / (24 * 18))):
+            x0 = int(torch.randint(0, W - 24, (1,), generator=g))
+            y0 = int(torch.randint(0, H - 18, (1,), generator=g))
+            depth[y0:y0 + 18, x0:x0 + 24] = 0.0
+    K = fp["K"].to(device)
+    pts = depth_to_points(depth.to(device), K)[::stride].contiguous()
+    rgb = fp["rgb"].to(device)[::stride].contiguous()
+    valid = pts[:, 2] > 0
+    scales = torch.full_like(pts, 1e-6)
+    scales[valid] = init_gs_scales(pts[valid].contiguous())
+    N = pts.shape[0]
+    sh = torch.zeros(N, 4, 3, device=device)
+    sh[:, 0, :] = (rgb - 0.5) / SH_C0
+    quats = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device).repeat(N, 1).contiguous()
+    return dict(means=pts, quats=quats, scales=scales.contiguous(), opacities=torch.ones(N, device=device), sh=sh, K=K,
+                W=W, H=H, N=N, viewmat=torch.linalg.inv(fp["c2w1"]).to(device).contiguous())

@@ -42,12 +42,6 @@ typedef enum gsl_status {
 const char* gsl_version(void);
 /* Text for a gsl_status. */
 const char* gsl_status_string(int status);
-/* Layout of the per-Gaussian records of the fused path.  1 (libgsloc_hip.so): Q0, Q1, Q2 are three arrays of
- * N float4.  4 (build variant libgsloc_hip_aos.so, -DGSL_QS=4, not yet measured): the three pointers address
- * columns 0, 1, 2 of ONE array of N rows of 4 float4 (64 bytes), i.e. Qk = base + 4*k floats and record g of Qk
- * lives at Qk + 16*g floats. */
-int gsl_record_stride(void);
-
 /* ---- projection: gsplat.fully_fused_projection fwd/bwd (IDX:14351, IDX:14270) ----
  * One camera.  viewmat[16] world->camera row-major, K[9] intrinsics, both on device.
  * Outputs for culled Gaussians: radii = 0, other outputs 0.
@@ -158,7 +152,12 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     -> radii, Q0, Q1, Q2, tile_offsets[n_tiles+1], n_isects[1]
  * gsl_fused_bin     : scatter + per-tile sort -> flatten_ids (isect_ids optional)
  * gsl_fused_raster_fwd / _bwd : compositing and its vjp; the vjp ACCUMULATES into vacc, 16 floats
- *                     per Gaussian ([v_xy 2][v_conic 3][v_opacity 1][v_colour channels]), zero on entry
+ *                     per Gaussian ([v_xy 2][v_conic 3][v_opacity 1][v_colour channels]), zero on entry.
+ *                     Forward: every lane walks the candidate list of its own pixel (csrc/raster_px.hip);
+ *                     backward: quadrant walk, per-splat pixel sums on the matrix cores
+ *                     (v_mfma_f32_16x16x4_f32, exact f32; csrc/fused.hip).  Only pixel rows [row0,row1)
+ *                     of the tile rows [ty0,ty1) are rendered / back-propagated (whole strip: 0,height):
+ *                     a strip's one-pixel Sobel halo costs one pixel row, not a tile row.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
  *                     v_viewmat[16] is overwritten (row 3 = 0). */
@@ -178,19 +177,13 @@ int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int 
 int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                         float* render, float* alphas, int32_t* last_ids, void* stream);
+                         float* render, float* alphas, int32_t* last_ids, int row0, int row1, void* stream);
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
-                         const float* v_render, const float* v_alphas, float* vacc, void* stream);
-/* gsl_fused_raster_bwd with the per-splat pixel sums on the matrix cores (v_mfma_f32_16x16x4_f32, exact f32):
- * same arguments, same vacc contract. */
-int gsl_mfma_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
-                        int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                        const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                        const float* render, const float* alphas, const int32_t* last_ids,
-                        const float* v_render, const float* v_alphas, float* vacc, void* stream);
+                         const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
+                         void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,
@@ -199,58 +192,22 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
 
-/* "Slab" backward for small splats: valid when every r_cull (Q1[:,3]) is < box/2 px (box = 4 or 8), i.e. no splat
- * reaches more than box x box pixel centres.  Replaces gsl_*_raster_bwd with the same vacc contract (rows are added
- * to, the projection backward reads and clears them).  Per-pixel walk, per-splat record slabs in LDS, no cross-lane
- * reduction.  flags (int32[1], may be NULL): flags[0] is set to 1 if a (pixel, splat) pair fell outside its slab,
- * i.e. the precondition did not hold and the gradients are incomplete -- the caller polls it and falls back. */
-int gsl_slab_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int box,
-                        int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                        const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                        const float* render, const float* alphas, const int32_t* last_ids,
-                        const float* v_render, const float* v_alphas, float* vacc, int32_t* flags,
-                        void* stream);
-
 /* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4
- * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_*_raster_bwd: instead of
+ * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_fused_raster_bwd: instead of
  * reducing and accumulating gradient rows it stores per (splat, pixel) records into trec[N][16][2] (zero on
  * entry) and the chained upstream gradient of every pixel into vcT[H,W,channels]; gsl_tiny_gather then sums
  * each Gaussian's 4x4 slab into its vacc row (overwritten, same layout as above) and clears the slab.
- * gsl_fused_project_bwd follows unchanged. */
+ * gsl_fused_project_bwd follows unchanged.  flags (int32[1], may be NULL): flags[0] is set to 1 when a
+ * (pixel, splat) pair fell outside its slab, i.e. the precondition did not hold and the gradients are
+ * incomplete -- the caller polls it and re-runs the iteration with gsl_fused_raster_bwd. */
 int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                         int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                         const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                         const float* render, const float* alphas, const int32_t* last_ids,
                         const float* v_render, const float* v_alphas, float* trec, float* vcT,
-                        void* stream);
+                        int row0, int row1, int32_t* flags, void* stream);
 int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
                     int height, float* trec, const float* vcT, float* vacc, void* stream);
-/* Experimental variant of gsl_tiny_gather (four lanes per Gaussian, csrc/experimental.hip): same contract; not
- * yet run on hardware and never selected by default (RenderContext: GSLOC_TINY_GATHER=4). */
-int gsl_tiny_gather4(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
-                     int height, float* trec, const float* vcT, float* vacc, void* stream);
-/* Experimental: gsl_tiny_gather and gsl_fused_project_bwd as ONE kernel (csrc/experimental.hip) -- the gradient
- * rows stay in shared memory.  Arguments of gsl_fused_project_bwd with `vacc` replaced by what the gather reads
- * (Q0, trec, vcT); trec is cleared as by gsl_tiny_gather.  Not yet run on hardware; RenderContext: GSLOC_TINY_FUSED=1. */
-int gsl_tiny_project_bwd(const float* means, const float* quats, const float* scales, const float* opacities,
-                         const float* colors, int sh_degree, int K_sh, const float* viewmat, const float* K, int N,
-                         int width, int height, float eps2d, int antialiased, int channels, const int32_t* radii,
-                         const float* Q0, const float* Q1, const float* compensations, float* trec, const float* vcT,
-                         float* v_means, float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
-                         float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
-
-/* Per-pixel-mask compositing (csrc/raster_px.hip): same contract and arguments as
- * gsl_fused_raster_fwd / gsl_fused_raster_bwd, a different kernel organisation: every lane walks the
- * candidate list of its own pixel, which suits the pixel-sized splats of the pose tracker. */
-int gsl_px_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
-                      int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                      const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                      float* render, float* alphas, int32_t* last_ids, void* stream);
-int gsl_px_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
-                      int width, int height, int tile_w, int tile_h, int ty0, int ty1,
-                      const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                      const float* render, const float* alphas, const int32_t* last_ids,
-                      const float* v_render, const float* v_alphas, float* vacc, void* stream);
 
 /* ---- tracker tail: loss + pose update on device (csrc/tracker.hip) ----
  * Replaces the PyTorch/kornia glue of one iteration of GsplatLoc's Runner.train
@@ -277,6 +234,12 @@ int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const floa
                   float depth_lambda, float edge_lambda, float beta1, float beta2, float eps,
                   float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
                   int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream);
+/* Several GPUs: what one rank contributes to the ONE all-reduce of an iteration.  out16[0..11] =
+ * v_viewmat[0..11] of its strip, out16[12..13] = its (sum |d - g|, sum |S(d) - S(g)|) over loss_partials[n][2]
+ * (fixed order), out16[14..15] = 0.  After the all-reduce (sum) gsl_pose_step takes v_viewmat = out16 and
+ * loss_sums = out16 + 12.  Written by a kernel of this library so that a captured iteration holds no foreign node. */
+int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials, float* out16,
+                         void* stream);
 
 /* ---- per-frame set-up: exact k nearest neighbours on the device (csrc/knn.hip) ----
  * Stands in for the small_gicp KdTree search of /root/reference/src/my_gsplat/utils.py:16-22.
@@ -289,10 +252,6 @@ int gsl_knn_cells(void);
 int gsl_knn_count(const float* points, int N, const float* bbox, void* ws, size_t ws_bytes, void* stream);
 int gsl_knn_query(const float* points, int N, const float* bbox, const int32_t* incl_offsets, int k,
                   float* dists, void* ws, size_t ws_bytes, void* stream);
-
-/* Self-test hook: out[l] = sum over the 64 lanes of in[lane][l/2] (the wave reduce-scatter the
- * compositing backward uses); one wave, in[64][32], out[64]. */
-int gsl_debug_reduce_scatter(const float* in, float* out, void* stream);
 
 #ifdef __cplusplus
 }

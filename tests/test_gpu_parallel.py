@@ -1,5 +1,6 @@
 """GPU (one device, ranks emulated in sequence): strip + halo rendering with pre-bucketed Gaussians and
-the shared loss reproduces the single-GPU tracker loss and pose gradient."""
+the shared loss reproduces the single-GPU tracker loss and pose gradient -- with a whole halo tile
+row composited, and with only the ONE halo pixel row the 3x3 Sobel needs (what GraphTracker does)."""
 import pytest
 import torch
 
@@ -9,10 +10,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def test_emulated_ranks_match_single_gpu():
+@pytest.mark.parametrize("pixel_halo", [False, True])
+def test_emulated_ranks_match_single_gpu(pixel_halo):
     import gsplatloc_amd.my_gsplat as M
     from gsplatloc_amd.context import RenderContext
-    from gsplatloc_amd.parallel import gaussians_for_strip, halo_rows, strip_rows, strip_tracking_loss
+    from gsplatloc_amd.parallel import gaussians_for_strip, halo_pixel_rows, halo_rows, strip_rows, strip_tracking_loss
     from oracle import tracker_oracle as T
 
     W, H = 160, 120
@@ -32,8 +34,9 @@ def test_emulated_ranks_match_single_gpu():
 
     def run(rows_render, rows_own, idx):
         sub = [t[idx].contiguous() for t in (pts0, quats, scales, opac, sh)] if idx is not None else [pts0, quats, scales, opac, sh]
+        px = halo_pixel_rows(rows_own, H) if (pixel_halo and rows_own is not None) else None
         rc = RenderContext(sub[0].shape[0], W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, tile_rows=rows_render,
-                           full_grads=False)
+                           pixel_rows=px, full_grads=False)
         rc.calibrate(*sub, viewmat, K)
         Vg = viewmat.clone().requires_grad_()
         render, _ = rc.render_autograd(*sub, Vg, K)

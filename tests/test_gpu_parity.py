@@ -366,16 +366,15 @@ def test_fused_tile_strip_matches_full_render():
     assert rel_inf(g_sum, g_full) < 1e-5
 
 
-@pytest.mark.parametrize("bwd,sigma_px", [("tiny", 0.0), ("slab4", 0.0), ("slab8", 0.0), ("slab8", 1.0)])
 @pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB+ED", False), ("RGB", True)])
-def test_small_splat_backwards_match_general_backward(mode, full, bwd, sigma_px, monkeypatch):
-    """RenderContext's backward variants for small splats -- "tiny" (4x4 record slabs in global memory, r_cull < 2 px),
-    "slab4" / "slab8" (per-pixel walk + per-splat slabs in LDS, r_cull < 2 / < 4 px) -- against the general
-    compositing backward (wave reduce-scatter) on the same render."""
+def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
+    """RenderContext picks the tiny-splat backward (4x4 record slabs, 4-lane gather, no atomics) when r_cull < 2 px;
+    its gradients must agree with the general compositing backward (quadrant walk, MFMA pixel sums) on the same
+    render."""
     A = _gpu()
     from gsplatloc_amd.context import RenderContext
     W, H, N = 200, 136, 30000
-    sc = _scene32(N, W, H, sigma_px=sigma_px)   # sigma 0: every splat is the 0.3 px^2 blur (radius 2); 1: radius 4
+    sc = _scene32(N, W, H, sigma_px=0.0)   # scales -> 0: every splat is the 0.3 px^2 blur (radius 2)
     sh = sh_from_rgb(sc["rgbs"]).to(DEV)
     ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
     V = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
@@ -387,41 +386,54 @@ def test_small_splat_backwards_match_general_backward(mode, full, bwd, sigma_px,
         v[..., :3] = 0  # the tracker's situation: only the depth channel carries a gradient
     va = torch.randn(H, W, 1, generator=gen).to(DEV)
     out = {}
-    for which in (bwd, "general"):
+    for which in ("auto", "general"):
         monkeypatch.setenv("GSLOC_BWD", which)
         rc = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=DEV, full_grads=full)
         rc.calibrate(*ins, V, K)
-        assert rc.tiny == (which == "tiny") and rc.slab == (int(which[-1]) if which.startswith("slab") else 0)
+        assert rc.tiny == (which == "auto")
         for _ in range(2):  # twice: the slabs / rows must come back clean
             rc.forward(*ins, V, K)
             g = rc.backward(v, va, full=full)
         rc.check_capacity()
         out[which] = {k: (t.clone() if t is not None else None) for k, t in g.items()}
-    assert rel_inf(out[bwd]["viewmat"], out["general"]["viewmat"]) < 2e-5
+    assert rel_inf(out["auto"]["viewmat"], out["general"]["viewmat"]) < 2e-5
     if full:
         for k in ("means", "scales", "opacities", "colors"):
             scale = float(out["general"][k].abs().max())
-            mostly_close(out[bwd][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
+            mostly_close(out["auto"][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
 
 
-def test_slab_backward_reports_a_splat_that_outgrew_its_slab(monkeypatch):
-    """Forcing the 4x4 slab backward on sigma_px = 1 splats (8 px wide): the kernel raises its sticky device flag
-    instead of dropping gradient silently, and check_capacity() turns it into an error."""
+def test_tiny_backward_reports_a_splat_that_outgrew_its_slab():
+    """A context calibrated on pixel-sized splats whose scales then grow (sigma_px = 1: 8+ px wide): the tiny
+    backward raises its sticky device flag instead of dropping gradient silently; the caller switches the context
+    to the general backward and gets the right gradient."""
     _gpu()
     from gsplatloc_amd.context import RenderContext
     W, H, N = 96, 64, 3000
-    sc = _scene32(N, W, H, sigma_px=1.0)
-    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
-    ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
+    small, big = _scene32(N, W, H, sigma_px=0.0), _scene32(N, W, H, sigma_px=1.0)
+    sh = sh_from_rgb(small["rgbs"]).to(DEV)
     V = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
-    K = sc["K"].to(DEV).contiguous()
-    monkeypatch.setenv("GSLOC_BWD", "slab4")
+    K = small["K"].to(DEV).contiguous()
+    ins = lambda sc: [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh, V, K]  # noqa: E731
+    v, va = torch.ones(H, W, 4, device=DEV), torch.zeros(H, W, 1, device=DEV)
     rc = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, full_grads=False)
-    rc.calibrate(*ins, V, K)
-    rc.forward(*ins, V, K)
-    rc.backward(torch.ones(H, W, 4, device=DEV), torch.zeros(H, W, 1, device=DEV), full=False)
+    rc.calibrate(*ins(small))
+    assert rc.tiny and not rc.tiny_overflowed()
+    rc.forward(*ins(big))
+    rc.backward(v, va, full=False)
+    assert rc.tiny_overflowed()
     with pytest.raises(RuntimeError, match="outgrew"):
         rc.check_capacity()
+    rc.use_general_backward()
+    rc.vacc.zero_()  # rows the interrupted tiny pass may have left
+    rc.forward(*ins(big))
+    got = rc.backward(v, va, full=False)["viewmat"].clone()
+    ref = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, full_grads=False)
+    ref.calibrate(*ins(big))
+    assert not ref.tiny
+    ref.forward(*ins(big))
+    want = ref.backward(v, va, full=False)["viewmat"]
+    assert rel_inf(got, want) < 1e-5
 
 
 def test_legacy_pair_on_the_gpu():

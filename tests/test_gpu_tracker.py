@@ -163,6 +163,32 @@ def test_graph_tracker_early_stop():
     assert abs(res.steps - ref.steps) <= 2, (res.steps, ref.steps)  # fp32 ties in "loss < best" may shift the stop by an iteration
 
 
+def test_graph_tracker_recovers_from_overflows():
+    """Neither a splat that outgrows the tiny backward nor an intersection list that outgrows its buffer costs the
+    frame: both are flagged on the device, read at the poll, and the frame is re-run from its initial pose with the
+    general backward / a larger buffer -- with the result of a tracker that had the right set-up from the start."""
+    M, fp, K, pts0, pts1, scales0, scales1 = _setup()
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    W, H = fp["W"], fp["H"]
+    src_depth = M.compute_depth_gt(pts1.to(DEV), fp["rgb"].to(DEV), K[None].to(DEV), torch.eye(4, device=DEV)[None], H, W)
+    cfg = M.TrackerConfig(max_steps=30, min_step=5, patience=1000)
+    big = torch.full_like(scales0, 6e-3).to(DEV)  # ~1.5 px at 2.5 m: r_cull > 2 px
+    frame = lambda sc: (pts0.to(DEV), fp["rgb"].to(DEV), sc, src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV), K.to(DEV))  # noqa: E731
+    ref = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10)
+    ref.load_frame(*frame(big))
+    assert not ref.rc.tiny
+    want = ref.run()
+    gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10)
+    gt.load_frame(*frame(scales0.to(DEV)))      # calibrated on the as-coded (pixel-sized) splats ...
+    assert gt.rc.tiny
+    gt.scales.copy_(big)                        # ... which then grow: tiny overflow AND more intersections
+    gt.rc._alloc_isects(int(gt.rc.n_is.item()) + 16)
+    got = gt.run()
+    assert not gt.rc.tiny and gt.rc.capacity > int(gt.rc.n_is.item())
+    assert got.steps == want.steps == 30
+    assert torch.allclose(torch.tensor(got.losses), torch.tensor(want.losses), rtol=1e-4)
+
+
 @pytest.mark.parametrize("case", ["depthmap", "random", "duplicates"])
 def test_device_knn_matches_kdtree(case):
     """csrc/knn.hip vs scipy cKDTree (the stand-in for small_gicp's KdTree, utils.py:16-22): exact k-NN."""

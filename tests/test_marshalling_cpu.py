@@ -15,21 +15,17 @@ def _expect_hip_refusal(fn, what):
     return what
 
 
-@pytest.mark.parametrize("mode,full,tiny,gather", [("RGB+ED", True, False, None), ("ED", False, True, None),
-                                                   ("RGB+ED", True, True, "4"), ("RGB", True, False, None),
-                                                   ("RGB+ED", True, True, "fused"), ("ED", False, True, "fused")])
-def test_render_context_stage_calls_marshal(mode, full, tiny, gather, monkeypatch):
+@pytest.mark.parametrize("mode,full,tiny,pixel_rows", [("RGB+ED", True, False, None), ("ED", False, True, None),
+                                                       ("RGB+ED", True, True, (15, 48)), ("RGB", True, False, (16, 33))])
+def test_render_context_stage_calls_marshal(mode, full, tiny, pixel_rows, monkeypatch):
     import gsplatloc_amd.context as CX
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
 
     monkeypatch.setattr(CX, "current_stream", lambda: None)
-    if gather == "fused":
-        monkeypatch.setenv("GSLOC_TINY_FUSED", "1")
-    elif gather:
-        monkeypatch.setenv("GSLOC_TINY_GATHER", gather)
     N, W, H = 500, 64, 48
-    ctx = CX.RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device="cpu", full_grads=full, tile_rows=(1, 3))
-    assert (ctx._tiny_gather is ctx.lib.gsl_tiny_gather4) == (gather == "4")
+    rows = (0, 3) if pixel_rows == (15, 48) else (1, 3)
+    ctx = CX.RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device="cpu", full_grads=full, tile_rows=rows,
+                           pixel_rows=pixel_rows)
     ctx._alloc_isects(4096)
     if tiny:
         ctx.tiny = True
@@ -46,15 +42,11 @@ def test_render_context_stage_calls_marshal(mode, full, tiny, gather, monkeypatc
     _expect_hip_refusal(lambda: ctx._raster_bwd(v, va), "raster bwd")
     if tiny:  # the first call of the pair already refused: exercise the gather on its own as well
         from gsplatloc_amd._lib import check, ptr
-        _expect_hip_refusal(lambda: check(ctx._tiny_gather(ptr(ctx.Q0), ptr(ctx.Q1), ptr(ctx.radii), ctx.N, ctx.D, ctx.W,
-                                                           ctx.H, ptr(ctx.trec), ptr(ctx.vcT), ptr(ctx.vacc), None),
-                                          "gsl_tiny_gather"), "gather")
-    if gather == "fused":
-        with pytest.raises(RuntimeError, match=r"gsl_tiny_project_bwd failed: HIP launch error \(status -3\)"):
-            ctx._project_bwd(full)
-    else:
-        with pytest.raises(RuntimeError, match=r"gsl_fused_project_bwd failed: HIP launch error \(status -3\)"):
-            ctx._project_bwd(full)
+        _expect_hip_refusal(lambda: check(ctx.lib.gsl_tiny_gather(ptr(ctx.Q0), ptr(ctx.Q1), ptr(ctx.radii), ctx.N, ctx.D,
+                                                                  ctx.W, ctx.H, ptr(ctx.trec), ptr(ctx.vcT), ptr(ctx.vacc),
+                                                                  None), "gsl_tiny_gather"), "gather")
+    with pytest.raises(RuntimeError, match=r"gsl_fused_project_bwd failed: HIP launch error \(status -3\)"):
+        ctx._project_bwd(full)
 
 
 def test_tracker_kernel_calls_marshal():
@@ -119,7 +111,7 @@ def test_graph_tracker_iteration_marshals_every_call(monkeypatch):
     assert calls[:n_setup] == ["gsl_pose_init", "gsl_fused_project"]
     # nothing was projected (the launch was refused), so every r_cull is 0 and calibration picked the tiny backward
     assert gt.rc.tiny
-    assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_bin", "raster_fwd", "gsl_tracking_loss",
+    assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_bin", "gsl_fused_raster_fwd", "gsl_tracking_loss",
                                "gsl_tiny_raster_bwd", "gsl_tiny_gather", "gsl_fused_project_bwd", "gsl_pose_step"]
 
 
@@ -220,13 +212,16 @@ rows = [(0, 2), (2, 3)][rank]                       # 3 tile rows split over the
 gt = GT.GraphTracker(pts.shape[0], W, H, TrackerConfig(max_steps=5), device="cpu", rows=rows, group=dist.group.WORLD)
 assert gt.render_rows == [(0, 3), (1, 3)][rank]      # one halo tile row towards the neighbour
 gt.load_frame(pts, fp["rgb"], torch.full((pts.shape[0], 3), 0.01), fp["depth1"], fp["c2w0"], fp["c2w1"], fp["K"])
-gt.rc.v_viewmat.fill_(float(rank + 1))               # what this rank's backward would have produced
-gt.partials.fill_(0.5)
+assert gt.pixel_rows == [(0, 33), (31, 48)][rank]    # of which ONE pixel row is composited
+# what gsl_pack_pose_reduce would have left (the launch is refused here): this rank's gradient and loss sums
+gt.reduce_buf[:12] = float(rank + 1)
+gt.reduce_buf[12:14] = torch.tensor([0.5 * gt.n_partials, 0.25 * gt.n_partials])
+mine = gt.reduce_buf[12:14].clone()
 gt._iteration()
-assert calls[-1] == "gsl_pose_step" and "gsl_tracking_loss" in calls
+assert calls[-1] == "gsl_pose_step" and "gsl_tracking_loss" in calls and "gsl_pack_pose_reduce" in calls
 assert torch.all(gt.reduce_buf[:12] == 3.0), gt.reduce_buf        # 1 + 2: the pose gradient of both strips
 sums = [torch.zeros(2) for _ in range(world)]
-dist.all_gather(sums, gt.partials.view(-1, 2).sum(0))
+dist.all_gather(sums, mine)
 assert torch.allclose(gt.reduce_buf[12:14], sums[0] + sums[1])    # loss sums of both strips
 print(f"rank {rank} ok", flush=True)
 dist.destroy_process_group()
