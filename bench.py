@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--sigma-px", type=float, default=None)
     ap.add_argument("--order", choices=["random", "raster"], default=None)
+    ap.add_argument("--staging", choices=["fp32", "fp16"], default=None,
+                    help="record precision of the compositing kernels (default: fp16 for workload X, BASELINE.json "
+                         "configs[4] 'fp16 compositing'; fp32 otherwise)")
     ap.add_argument("--pose-only", action="store_true", help="skip per-Gaussian gradient outputs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the parity block")
     ap.add_argument("--cpu-sample-div", type=int, default=3,
@@ -71,6 +74,8 @@ def parse():
             setattr(args, key, wl.get(key, {"sigma_px": 0.0, "order": "raster"}.get(key)))
     # explicit sizes always mean the random-N scene; the depth-frame workloads are selected by name only
     args.kind = "random" if (explicit or wl["kind"] == "random") else "depth_frame"
+    if args.staging is None:
+        args.staging = "fp16" if (args.workload == "X" and not explicit) else "fp32"
     return args
 
 
@@ -152,40 +157,51 @@ def cpu_baseline(args, scene, gpu):
     arrays = [scene[k].cpu().numpy() for k in ("means", "quats", "scales", "opacities", "sh")] + [V.numpy(), scene["K"].cpu().numpy()]
     v = gpu["v_render"].cpu().numpy()
 
-    def step(precision="f32", v_render=v):
+    def step(precision="f32", v_render=v, threads=cores):
         return c_oracle.rasterization(*arrays, w, h, sh_degree=1, render_mode="RGB+ED", v_render=v_render,
-                                      precision=precision, threads=cores)
+                                      precision=precision, threads=threads)
 
-    step()
-    ts = []
-    for _ in range(2):
-        t = time.perf_counter()
-        out = step()
-        ts.append(time.perf_counter() - t)
-    dt = min(ts)
-    base = {"value": n / dt, "unit": "Gaussians/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/csrc/gsplat_oracle.c float32 + OpenMP on {cores} threads, the full workload (N={n}, "
-                      f"{w}x{h}, {out['n_isects']} intersections), fwd+bwd with all gradients, best of 2 after one "
-                      f"warm-up step, {dt:.2f} s/step"}
+    # the port's OpenMP loops do not scale to every core of a large host: time a few thread counts (one warm-up and
+    # two timed steps each) and report the fastest, with the thread count it used
+    best = None
+    for threads in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
+        step(threads=threads)
+        for _ in range(2):
+            t = time.perf_counter()
+            out = step(threads=threads)
+            d = time.perf_counter() - t
+            if best is None or d < best[0]:
+                best = (d, threads)
+    dt, used = best
+    base = {"value": n / dt, "unit": "Gaussians/s", "cores": used, "kind": "port",
+            "sample": f"oracle/csrc/gsplat_oracle.c float32 + OpenMP, fastest of {{all, 64, 16}} threads on a {cores}-core "
+                      f"host = {used} threads, the full workload (N={n}, {w}x{h}, {out['n_isects']} intersections), "
+                      f"fwd+bwd with all gradients, best of 2 after one warm-up step, {dt:.2f} s/step"}
     parity = None
     if gpu.get("render") is not None:
         import numpy as np
         ref = step("f64", None)
         rg, ag = gpu["render"].cpu().double().numpy(), gpu["alphas"].cpu().double().numpy()[..., 0]
         d_rel = np.abs(rg[..., 3] - ref["render"][..., 3]) / np.maximum(np.abs(ref["render"][..., 3]), 1e-3)
-        ok = (np.abs(rg - ref["render"]) <= 2e-5 + 1e-4 * np.abs(ref["render"])).all(-1) & (
-            np.abs(ag - ref["alphas"]) <= 2e-5 + 1e-4 * np.abs(ref["alphas"]))
+        rt, at = (1e-4, 2e-5) if args.staging == "fp32" else (3e-3, 3e-4)
+        ok = (np.abs(rg - ref["render"]) <= at + rt * np.abs(ref["render"])).all(-1) & (
+            np.abs(ag - ref["alphas"]) <= at + rt * np.abs(ref["alphas"]))
         vm = v * ok[..., None]
         want = step("f64", vm)
         got = gpu["backward"](torch.from_numpy(vm))
         gv, wv = got.cpu().double().numpy()[:3], want["v_viewmat"][:3]
-        parity = {"against": "oracle/csrc/gsplat_oracle.c float64", "tolerance": "1e-4 relative (north_star)",
+        parity = {"against": "oracle/csrc/gsplat_oracle.c float64",
+                  "tolerance": "1e-4 relative (north_star)" if args.staging == "fp32" else
+                               "fp16-staged records: ~1e-3 relative expected (half has 11 significant bits)",
                   "depth_rel_err": {"mean": float(d_rel.mean()), "p99": float(np.quantile(d_rel.reshape(-1)[::7], 0.99)),
                                     "max_over_agreeing_pixels": float(d_rel[ok].max())},
                   "alpha_abs_err": {"mean": float(np.abs(ag - ref["alphas"]).mean()),
                                     "max_over_agreeing_pixels": float(np.abs(ag - ref["alphas"])[ok].max())},
                   "pixels_beyond_tolerance": float(1.0 - ok.mean()),
                   "v_viewmat_rel_err": float(np.abs(gv - wv).max() / np.abs(wv).max()),
+                  "v_viewmat_note": "upstream gradient = white noise on the depth channel: a sum of ~1e6 terms of random "
+                                    "sign, i.e. the worst conditioning; with the tracker's loss as the upstream gradient "
+                                    "the error is ~1e-5 (tests/test_gpu_configs.py)",
                   "n_isects": [int(gpu["n_isects"]), int(ref["n_isects"])]}
     return base, parity
 
@@ -352,20 +368,22 @@ def main():
     # ---- tile-row strip of this rank (balanced on a calibration pass) -------------------------
     rows = (0, th)
     n_local = N
-    if world > 1:
+    diag = os.environ.get("GSLOC_DIAG", "")  # diagnosis of the N > 1 graph-replay fault (scripts/gpu_rehearse.sh)
+    if world > 1 or "strip" in diag:
         # once per frame (untimed): balance strips on a full binning pass, keep the Gaussians that can reach
         # this rank's strip (1-tile guard band), the rest never touch its pixels
         from gsplatloc_amd.parallel import gaussians_for_strip
         cal = C.RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
         cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
-        rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank]
+        rows = strip_rows(cal.offs, cal.tw, cal.th, max(world, 2))[rank]
         idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
         for k in sc:
             sc[k] = sc[k][idx].contiguous()
         n_local = int(idx.numel())
         del cal
         trace(f"strip rows {rows}, {n_local} local Gaussians")
-    ctx = C.RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full)
+    ctx = C.RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full,
+                          staging=args.staging)
     n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
     trace(f"calibrated, {n_isects} intersections")
     g = torch.Generator().manual_seed(1)
@@ -375,31 +393,33 @@ def main():
     v_alphas = torch.zeros(H, W, 1, device=dev)
     pose_grad = torch.zeros(16, device=dev)  # this rank's 16 floats of the all-reduce
     host16 = None
-    if dist is not None and args.rehearse_on_one_gpu:
+    if (dist is not None and args.rehearse_on_one_gpu) or "hostcopy" in diag:
         host16 = torch.zeros(16).pin_memory()
+    if diag:
+        for name, t in list(vars(ctx).items()) + [("pose_grad", pose_grad), ("host16", host16), ("v_render", v_render)]:
+            if torch.is_tensor(t):
+                print(f"[diag rank {rank}] {name:12s} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}",
+                      file=sys.stderr, flush=True)
     args_in = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
 
     def render_step():
         """The rank's launches of one step: library kernels and memsets only (captured as one HIP graph)."""
         ctx.forward(*args_in)
         grads = ctx.backward(v_render, v_alphas, full=full)
-        if dist is not None:  # pack the 12 pose-gradient entries (+4 spare) into the all-reduce buffer
-            if os.environ.get("GSLOC_DIAG_CAPTURED_COPY"):  # diagnosis of round 1's fault: a torch copy node in the graph
-                pose_grad.copy_(grads["viewmat"].reshape(16))
-            else:
-                C.pack_pose_reduce(grads["viewmat"], pose_grad)
+        if dist is not None or diag:  # pack the 12 pose-gradient entries (+4 spare) into the all-reduce buffer
+            C.pack_pose_reduce(grads["viewmat"], pose_grad)
 
     def collective():
         """THE collective of the path: one all-reduce of 16 floats (RCCL on the device buffer; the one-GPU
         rehearsal's gloo group goes through a pinned host buffer)."""
-        if host16 is not None and os.environ.get("GSLOC_DIAG_PAGEABLE"):  # diagnosis: round 1's pageable host path
-            host = pose_grad.cpu()
-            dist.all_reduce(host)
-            pose_grad.copy_(host)
+        if "nocopy" in diag:       # diagnosis: graph replays of two processes, no copies between them
+            if dist is not None:
+                dist.barrier()
         elif host16 is not None:
             host16.copy_(pose_grad, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            dist.all_reduce(host16)
+            if dist is not None:
+                dist.all_reduce(host16)
             pose_grad.copy_(host16, non_blocking=True)
         else:
             dist.all_reduce(pose_grad)
@@ -421,7 +441,7 @@ def main():
 
     def run():
         render()
-        if dist is not None:
+        if dist is not None or "hostcopy" in diag:
             collective()
 
     for _ in range(args.warmup):
@@ -485,7 +505,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",  # the frame (N Gaussians, one image) is fixed; more GPUs split its tile rows
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.staging == "fp32" else "f32 (f16-staged records)",
             "data": "synthetic",
             "config": {
                 "workload": what + ", render_mode=RGB+ED sh_degree=1, backward from a depth-channel gradient, "
@@ -495,6 +515,7 @@ def main():
                 "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
                 "launch": "hipGraph replay" if graph is not None else "eager",
                 "backward": backward_name(ctx),
+                "staging": args.staging + (" records for compositing (T and accumulators f32)" if args.staging == "fp16" else ""),
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

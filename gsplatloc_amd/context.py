@@ -30,7 +30,7 @@ class RenderContext:
                  K_sh: int = 4, device="cuda", eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10,
                  radius_clip: float = 0.0, antialiased: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
                  capacity: Optional[int] = None, full_grads: bool = True,
-                 pixel_rows: Optional[Tuple[int, int]] = None):
+                 pixel_rows: Optional[Tuple[int, int]] = None, staging: str = "fp32"):
         self.lib = load_library()
         self.N, self.W, self.H = int(N), int(width), int(height)
         self.mode = render_mode
@@ -56,6 +56,11 @@ class RenderContext:
         N = self.N
         self.radii = torch.zeros(N, dtype=i32, device=dev)
         self.Q0, self.Q1, self.Q2 = alloc_records(self.lib, N, self.rgb, dev, zero=True)
+        # "fp16": the compositing kernels gather one 32-byte half-precision record per splat (BASELINE.json configs[4]);
+        # transmittance and all accumulators stay float32
+        assert staging in ("fp32", "fp16"), staging
+        self.staging = staging
+        self.Qh = torch.zeros(N, 8, dtype=i32, device=dev) if staging == "fp16" else None
         self.comps = torch.zeros(N, dtype=f32, device=dev) if self.antialiased else None
         self.offs = torch.zeros(self.n_tiles + 1, dtype=i32, device=dev)
         self.n_is = torch.zeros(1, dtype=i32, device=dev)
@@ -107,7 +112,7 @@ class RenderContext:
         compositing backward.  GSLOC_BWD=general disables it (dev switch)."""
         import os
         r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
-        want = os.environ.get("GSLOC_BWD", "auto") != "general" and r_max < TINY_RCULL_MAX
+        want = os.environ.get("GSLOC_BWD", "auto") != "general" and r_max < TINY_RCULL_MAX and self.Qh is None
         if want and self.trec is None:
             self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
             self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
@@ -141,7 +146,7 @@ class RenderContext:
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, self.near, self.far,
             self.radius_clip, int(self.antialiased), self.tw, self.th, self.ty0, self.ty1, ptr(self.radii),
             ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), ptr(self.comps), None, ptr(self.offs), ptr(self.n_is),
-            ptr(self.ws), self.ws_bytes, current_stream()), "gsl_fused_project")
+            ptr(self.ws), self.ws_bytes, ptr(self.Qh), current_stream()), "gsl_fused_project")
 
     def _bin(self) -> None:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
@@ -153,7 +158,7 @@ class RenderContext:
         check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
-                                            ptr(self.last_ids), self.row0, self.row1, current_stream()),
+                                            ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh), current_stream()),
               "gsl_fused_raster_fwd")
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
@@ -167,8 +172,8 @@ class RenderContext:
                                            ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
                   "gsl_tiny_gather")
         else:
-            check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, current_stream()),
-                  "gsl_fused_raster_bwd")
+            check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
+                                                current_stream()), "gsl_fused_raster_bwd")
 
     def _project_bwd(self, full: bool) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs

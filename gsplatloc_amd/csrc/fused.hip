@@ -57,7 +57,8 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     const float* __restrict__ V, const float* __restrict__ Kmat, int N, int W, int H, float eps2d, float near_plane,
     float far_plane, float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
     int32_t* __restrict__ radii, float4* __restrict__ Q0, float4* __restrict__ Q1, float4* __restrict__ Q2,
-    float* __restrict__ comps, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts) {
+    float* __restrict__ comps, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts,
+    uint4* __restrict__ Qh) {
   extern __shared__ int s_hist[];
   int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
   for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) s_hist[k] = 0;
@@ -106,8 +107,8 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     GSL_Q(Q0, i) = o0;
     GSL_Q(Q1, i) = o1;
     if (comps) comps[i] = comp;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (RGB) {
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
       if (sh_degree < 0) {
         c0 = colors[3 * (size_t)i]; c1 = colors[3 * (size_t)i + 1]; c2 = colors[3 * (size_t)i + 2];
       } else {
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
       }
       GSL_Q(Q2, i) = make_float4(c0, c1, c2, 0.f);
     }
+    if (Qh) store_half_record(Qh, (size_t)i, o0, o1, make_float4(c0, c1, c2, 0.f));
     if (radius > 0) {
       tile_rect(o0.x, o0.y, radius, 16, tile_w, tile_h, xmin, ymin, xmax, ymax);
       ymin = max(ymin, ty0);
@@ -331,9 +333,9 @@ __device__ __forceinline__ void mraster_group_flush(FStageM<D>& sb, int wv, int 
 template <int D, int CG>
 __device__ __forceinline__ void mraster_bwd_body(
     FStageM<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
-    const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs, long long re, int nb, int tid,
-    float px, float py, float qcx, float qcy, float tcx, float tcy, bool inside, int bin_final, int wave_final,
-    float T_final, const float (&vc)[D], float va) {
+    const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs,
+    long long re, int nb, int tid, float px, float py, float qcx, float qcy, float tcx, float tcy, bool inside,
+    int bin_final, int wave_final, float T_final, const float (&vc)[D], float va) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   constexpr int A = FStageM<D>::A;
@@ -391,9 +393,7 @@ __device__ __forceinline__ void mraster_bwd_body(
     int bsize = (int)min((long long)GSL_MB, bend + 1 - rs);
     if (tid < bsize) {
       pg = flatten_ids[bend - tid];
-      pr0 = GSL_Q(Q0, pg);
-      pr1 = GSL_Q(Q1, pg);
-      if (RGB && CG == D) pr2 = GSL_Q(Q2, pg);
+      load_record(Q0, Q1, Q2, Qh, pg, RGB && CG == D, pr0, pr1, pr2);
     }
   };
   gather(0);
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void k_mraster_bwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc, int row0, int row1) {
+    float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh) {
   __shared__ FStageM<D> sb;
   __shared__ int s_final[4];
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
@@ -587,10 +587,10 @@ __global__ __launch_bounds__(256) void k_mraster_bwd(
   if (rs >= re) return;
   int nb = (int)((re - rs + GSL_MB - 1) / GSL_MB);
   if (D == 4 && !any_rgb)
-    mraster_bwd_body<D, 1>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
+    mraster_bwd_body<D, 1>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
                            bin_final, wave_final, T_final, vc, va);
   else
-    mraster_bwd_body<D, D>(sb, Q0, Q1, Q2, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
+    mraster_bwd_body<D, D>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
                            bin_final, wave_final, T_final, vc, va);
 }
 
@@ -770,7 +770,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
                                  float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
                                  int32_t* radii, float* Q0, float* Q1, float* Q2, float* compensations,
                                  int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
-                                 size_t ws_bytes, void* stream) {
+                                 size_t ws_bytes, void* Qh, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
@@ -793,12 +793,12 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
       hipLaunchKernelGGL(gsl::k_fproject<true>, grid, block, lds, st, means, quats, scales, opacities, colors,
                          sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,
                          antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,
-                         compensations, tiles_per_gauss, counts);
+                         compensations, tiles_per_gauss, counts, (uint4*)Qh);
     else
       hipLaunchKernelGGL(gsl::k_fproject<false>, grid, block, lds, st, means, quats, scales, opacities, colors,
                          sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,
                          antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,
-                         compensations, tiles_per_gauss, counts);
+                         compensations, tiles_per_gauss, counts, (uint4*)Qh);
     GSL_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(gsl::k_ftile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors);
@@ -843,7 +843,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                    const float* render, const float* alphas, const int32_t* last_ids,
                                    const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                                   void* stream) {
+                                   const void* Qh, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -851,14 +851,15 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (capacity == 0 || ty0 == ty1 || row0 == row1) return GSL_OK;
-  if (!Q0 || !Q1 || !flatten_ids || !vacc || (channels >= 3 && !Q2)) return GSL_ERR_BAD_ARG;
+  if (!flatten_ids || !vacc) return GSL_ERR_BAD_ARG;
+  if (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
 #define CALL_MB(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,    \
-                     row0, row1)
+                     row0, row1, (const uint4*)Qh)
   GSL_F_DISPATCH(channels, ed, CALL_MB)
 #undef CALL_MB
   GSL_CHECK_LAUNCH();

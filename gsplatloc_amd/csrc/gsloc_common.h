@@ -98,6 +98,41 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
 #define GSL_Q(arr, g) (arr)[(g)]
 #define GSL_TILE_OF_BLOCK() blockIdx.x
 
+// ---- fp16-staged records (workload X, "fp16 compositing": BASELINE.json configs[4]) --------------------
+// One 32-byte record per Gaussian for the compositing kernels instead of three 16-byte ones: the centre stays float32
+// (a 1920-px coordinate needs it), conic, cull radius, depth feature, opacity and colour are halves.  Everything the
+// compositing loops accumulate (T, colour sums, gradient sums) stays float32: the records are widened when they are
+// staged in LDS, so the loops themselves are the float32 ones.
+//   dw0 x   dw1 y   dw2 (conic a | b)   dw3 (conic c | r_cull, rounded up)   dw4 (depth | opacity)   dw5 (r | g)   dw6 (b | 0)
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+  _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ float h_lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xFFFFu)); }
+__device__ __forceinline__ float h_hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
+__device__ __forceinline__ void store_half_record(uint4* __restrict__ Qh, size_t i, float4 q0, float4 q1, float4 q2) {
+  float rc = (q1.w > 0.f && q1.w < 6.0e4f) ? q1.w * 1.002f + 0.01f : q1.w;  // conservative radius: never rounded down
+  Qh[2 * i] = make_uint4(__float_as_uint(q0.x), __float_as_uint(q0.y), pack2h(q1.x, q1.y), pack2h(q1.z, rc));
+  Qh[2 * i + 1] = make_uint4(pack2h(q0.z, q0.w), pack2h(q2.x, q2.y), pack2h(q2.z, 0.f), 0u);
+}
+
+// Record g for the compositing kernels: the float32 arrays, or the fp16-staged array when Qh is given.
+__device__ __forceinline__ void load_record(const float4* __restrict__ Q0, const float4* __restrict__ Q1,
+                                            const float4* __restrict__ Q2, const uint4* __restrict__ Qh, int g,
+                                            bool want_rgb, float4& r0, float4& r1, float4& r2) {
+  if (Qh) {
+    uint4 lo = Qh[2 * (size_t)g], hi = Qh[2 * (size_t)g + 1];
+    r0 = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), h_lo(hi.x), h_hi(hi.x));
+    r1 = make_float4(h_lo(lo.z), h_hi(lo.z), h_lo(lo.w), h_hi(lo.w));
+    r2 = make_float4(h_lo(hi.y), h_hi(hi.y), h_lo(hi.z), 0.f);
+  } else {
+    r0 = GSL_Q(Q0, g);
+    r1 = GSL_Q(Q1, g);
+    if (want_rgb) r2 = GSL_Q(Q2, g);
+  }
+}
+
 // DPP lane exchange (no LDS traffic).  Lanes a row_mask disables contribute 0.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_get(float v) {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-    int row0, int row1) {
+    int row0, int row1, const uint4* __restrict__ Qh) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ PStage<D> sb;
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
     if (tid < bsize) {
       int g = flatten_ids[bstart + tid];
-      r0 = GSL_Q(Q0, g);
-      r1 = GSL_Q(Q1, g);
+      float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      load_record(Q0, Q1, Q2, Qh, g, RGB, r0, r1, r2);
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
-      if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
+      if (RGB) sb.s2[tid] = r2;
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     for (int c = 0; c < n; c += 64) {
@@ -499,14 +499,14 @@ extern "C" int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* 
 extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
-                                 int32_t* last_ids, int row0, int row1, void* stream) {
+                                 int32_t* last_ids, int row0, int row1, const void* Qh, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
   if (!tile_offsets || !render || !alphas || !last_ids) return GSL_ERR_BAD_ARG;
-  if (capacity > 0 && (!Q0 || !Q1 || !flatten_ids)) return GSL_ERR_BAD_ARG;
-  if (channels >= 3 && capacity > 0 && !Q2) return GSL_ERR_BAD_ARG;
+  if (capacity > 0 && !flatten_ids) return GSL_ERR_BAD_ARG;
+  if (capacity > 0 && !Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (ty0 == ty1) return GSL_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -514,7 +514,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
 #define CALL_PF(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1)
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();

@@ -61,7 +61,7 @@ class _FusedRasterization(torch.autograd.Function):
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rgb else None, sh_degree, K_sh,
             ptr(viewmat), ptr(K), N, W, H, eps2d, near, far, radius_clip, int(antialiased), tw, th, ty0, ty1,
             ptr(radii), ptr(Q0), ptr(Q1), ptr(Q2), ptr(comps), ptr(tpg), ptr(offs), ptr(n_is), ptr(ws), ws_bytes,
-            st), "gsl_fused_project")
+            None, st), "gsl_fused_project")
         n_isects = int(n_is.item())  # output sizes depend on it (gsplat syncs at the same point)
         cap = max(n_isects, 1)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -78,7 +78,7 @@ class _FusedRasterization(torch.autograd.Function):
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
-                                       ptr(last_ids), 0, H, st), "gsl_fused_raster_fwd")
+                                       ptr(last_ids), 0, H, None, st), "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
                               comps if antialiased else torch.empty(0, device=dev), offs, flatten_ids, render,
@@ -114,7 +114,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(vacc), 0, H, st), "gsl_fused_raster_bwd")
+                                       ptr(vacc), 0, H, None, st), "gsl_fused_raster_bwd")
         ni = ctx.needs_input_grad
         full = any(ni[:5])
         v_means = v_quats = v_scales = v_opac = v_colors = None

@@ -102,10 +102,17 @@ def depth_frame_scene(W: int = 640, H: int = 480, stride: int = 1, holes: bool =
     synthetic room depth image back-projected in raster order, isotropic scales from the 4 nearest neighbours as the
     reference codes them (device k-NN), opacity 1, SH degree 1 with a random DC colour.  ``holes`` zeroes rectangular
     patches of the depth image as a TUM frame has them: those points sit at the camera origin and are culled by the
-    near plane.  Rendered from the frame pair's second pose.  Needs the GPU (k-NN kernels)."""
+    near plane.  Rendered from the frame pair's second pose, chosen so that the camera has moved FORWARD: the invalid
+    points then lie behind the near plane as SURVEY.md A.7 describes the usual case (with a sideways or backward
+    step they are splatted as one enormous pile at the image centre -- handled, tests/test_gpu_configs.py has that
+    frame, but it measures the pile, not the frame).  Needs the GPU (k-NN kernels)."""
     from .my_gsplat.geometry import depth_to_points, init_gs_scales
 
     fp = frame_pair(W, H, rot_deg=0.4, trans=0.015, seed=seed)
+    c2w1 = fp["c2w1"].clone()
+    if float((-c2w1[:3, :3].T @ c2w1[:3, 3])[2]) > 0:  # world origin in front of the second camera: step the other way
+        c2w1[:3, 3] = -c2w1[:3, 3]
+    fp["c2w1"] = c2w1
     depth = fp["depth0"].clone()
     if holes:
         g = torch.Generator().manual_seed(seed)

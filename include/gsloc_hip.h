@@ -158,6 +158,12 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     (v_mfma_f32_16x16x4_f32, exact f32; csrc/fused.hip).  Only pixel rows [row0,row1)
  *                     of the tile rows [ty0,ty1) are rendered / back-propagated (whole strip: 0,height):
  *                     a strip's one-pixel Sobel halo costs one pixel row, not a tile row.
+ * fp16 staging (Qh, may be NULL everywhere): gsl_fused_project additionally packs one 32-byte record per Gaussian
+ *                     into Qh[N][8 dwords] -- centre float32, conic / cull radius / depth / opacity / colour as
+ *                     halves -- and the compositing calls given Qh gather that record instead of Q0/Q1/Q2 (which may
+ *                     then be NULL there).  Transmittance and every accumulator stay float32 (BASELINE.json
+ *                     configs[4] "fp16 compositing").  Binning and gsl_fused_project_bwd keep reading
+ *                     the float32 records, so the list order is the float32 order.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
  *                     v_viewmat[16] is overwritten (row 3 = 0). */
@@ -169,7 +175,7 @@ int gsl_fused_project(const float* means, const float* quats, const float* scale
                       int antialiased, int tile_w, int tile_h, int ty0, int ty1, int32_t* radii,
                       float* Q0, float* Q1, float* Q2, float* compensations,
                       int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
-                      size_t ws_bytes, void* stream);
+                      size_t ws_bytes, void* Qh, void* stream);
 int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0,
                   int ty1, int tile_n_bits, const int32_t* tile_offsets, int64_t capacity,
                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
@@ -177,13 +183,14 @@ int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int 
 int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
-                         float* render, float* alphas, int32_t* last_ids, int row0, int row1, void* stream);
+                         float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
+                         void* stream);
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                         void* stream);
+                         const void* Qh, void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,

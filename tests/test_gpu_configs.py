@@ -169,3 +169,90 @@ def test_config_S_tracker_200_iterations():
     e0 = M.calculate_translation_error(fp["c2w0"], fp["c2w1"])
     assert res.best_eT < 0.1 * e0, (res.best_eT, e0)
     assert res.best_loss == pytest.approx(float(losses[101:].min()), rel=1e-6)  # min-loss read-out after step 100
+
+
+def test_config_X_fp16_staged_compositing():
+    """BASELINE.json configs[4]: 5 M random Gaussians, 1920x1080, "fp16 compositing" -- the compositing kernels gather
+    32-byte half-precision records (centre float32; conic, depth, opacity, colour half), transmittance and every
+    accumulator float32.  Checked against the float64 oracle at the precision half records allow
+    (11 significant bits: 3e-3 relative, stated here), and against the float32-staged HIP path."""
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+    from oracle import c_oracle as C
+
+    dev = torch.device("cuda")
+    N, W, H = 5_000_000, 1920, 1080
+    sc = random_scene(N, W, H, sigma_px=1.0, order="random")
+    V = torch.linalg.inv(perturbed_pose())
+    cpu = [sc[k] for k in ("means", "quats", "scales", "opacities", "sh")]
+    inp = tuple(t.to(dev).contiguous() for t in cpu) + (V.to(dev).contiguous(), sc["K"].to(dev).contiguous())
+    v = _depth_upstream(H, W)
+    out = {}
+    for staging in ("fp16", "fp32"):
+        ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False, staging=staging)
+        n_is = ctx.calibrate(*inp)
+        render, alphas = ctx.forward(*inp)
+        g = ctx.backward(v.float().to(dev).contiguous(), torch.zeros(H, W, 1, device=dev), full=False)
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        out[staging] = (render.cpu().double(), alphas.cpu().double(), g["viewmat"].cpu().double().clone(), n_is)
+        del ctx
+    r16, a16, g16, n16 = out["fp16"]
+    r32, a32, g32, n32 = out["fp32"]
+    assert n16 == n32  # binning reads the float32 records: same lists
+    want = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", precision="f64", threads=THREADS)
+    ref_r, ref_a = torch.from_numpy(want["render"]), torch.from_numpy(want["alphas"])[..., None]
+    bad = 1.0 - agreeing_pixels(r16, a16, ref_r, ref_a, rtol=3e-3, atol=3e-4).double().mean().item()
+    drel = ((r16[..., 3] - ref_r[..., 3]).abs() / ref_r[..., 3].abs().clamp(min=1e-3))
+    pose = rel_inf(g16[:3], g32[:3])
+    report("X fp16-staged", bad, depth_rel_mean=float(drel.mean()), depth_rel_p99=float(torch.quantile(drel.reshape(-1)[::37], 0.99)),
+           v_viewmat_vs_fp32_staging=pose)
+    assert bad < 5e-3, bad
+    assert float(drel.mean()) < 5e-4
+    assert pose < 2e-2, pose  # the gradient of a render whose records carry 5e-4 relative rounding
+
+
+@pytest.mark.parametrize("stride,holes", [(3, False), (1, True)])
+def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
+    """north_star's pose-gradient statement as the tracker poses it: d loss / d viewmat of GsplatLoc's depth + Sobel
+    loss (/root/reference/src/my_gsplat/gs_trainer_total.py:105-150) on the frames of configs S (102 400 Gaussians) and
+    T (307 200, invalid depths), 640x480, HIP (render, fused loss kernel, backward) against the oracle (C rasterizer
+    in float64 + the restated loss under autograd).  1e-4 of the largest entry."""
+    from gsplatloc_amd._lib import check, current_stream, load_library, ptr
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+    from oracle import tracker_oracle as T
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=stride, holes=holes, device=dev)
+    N = sc["means"].shape[0]
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
+    # target depth: the same cloud seen from a slightly different pose (any fixed image would do)
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
+    ctx.calibrate(*inp)
+    V2 = sc["viewmat"].clone()
+    V2[0, 3] += 0.004
+    render, _ = ctx.forward(*inp[:5], V2.contiguous(), inp[6])
+    gt = render[..., 3].clone()
+    render, _ = ctx.forward(*inp)
+    lib = load_library()
+    ws_bytes = lib.gsl_loss_ws_bytes(W, H)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+    v_render = torch.zeros(H, W, 4, device=dev)
+    partials = torch.zeros(((H * W + 255) // 256) * 2, device=dev)
+    check(lib.gsl_tracking_loss(ptr(ctx.render), 4, ptr(gt), W, H, 0, H, 0.8, 0.2, ptr(v_render), ptr(partials), None,
+                                ptr(ws), ws_bytes, current_stream()), "gsl_tracking_loss")
+    got = ctx.backward(v_render, torch.zeros(H, W, 1, device=dev), full=False)["viewmat"].cpu().double()
+    loss_g = float(0.8 * partials.view(-1, 2)[:, 0].sum() + 0.2 * partials.view(-1, 2)[:, 1].sum()) / (W * H)
+    # oracle: float64 C rasterizer under autograd + the restated loss
+    Vo = sc["viewmat"].cpu().double().requires_grad_()
+    cpu = [sc[k].cpu().double() for k in ("means", "quats", "scales", "opacities", "sh")]
+    renders, _ = T._CRasterize.apply(Vo, *cpu, sc["K"].cpu().double(), W, H, THREADS)
+    total, _, _ = T.tracking_loss(renders[..., 3:4], gt.cpu().double()[None, ..., None])
+    total.backward()
+    err = rel_inf(got[:3], Vo.grad[:3])
+    report(f"tracker-loss pose gradient, {N} Gaussians 640x480", 0.0, loss_rel=abs(loss_g - float(total)) / float(total),
+           v_viewmat=err)
+    assert abs(loss_g - float(total)) < 1e-4 * float(total)
+    assert err < POSE_GRAD_TOL, err
