@@ -206,11 +206,16 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   // pose errors of the CURRENT pose vs ground truth (eval/utils.py:122-168)
   float dt0 = t[0] - gt_c2w[3], dt1 = t[1] - gt_c2w[7], dt2 = t[2] - gt_c2w[11];
   float eT = sqrtf(dt0 * dt0 + dt1 * dt1 + dt2 * dt2);
-  float tr = 0.f;  // trace(R_est R_gt^T) = sum_ij R_est[i][j] * R_gt[i][j]
+  // rotation angle of R_est R_gt^T (eval/utils.py:144-168 takes acos((trace - 1) / 2)).  In float32 that form
+  // resolves angles only down to sqrt(2 * 6e-8) rad = 0.02 degrees -- the level of the reference's own AAE table --
+  // so the same angle is computed from the difference of the matrices:  |R_est - R_gt|_F^2 = 8 sin^2(theta / 2).
+  float fro = 0.f;
   for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) tr += R[i * 3 + j] * gt_c2w[i * 4 + j];
-  float cs = fminf(1.f, fmaxf(-1.f, (tr - 1.f) * 0.5f));
-  float eR = acosf(cs) * 57.29577951308232f;
+    for (int j = 0; j < 3; ++j) {
+      float d = R[i * 3 + j] - gt_c2w[i * 4 + j];
+      fro += d * d;
+    }
+  float eR = 2.f * asinf(fminf(1.f, sqrtf(fro * 0.125f))) * 57.29577951308232f;
   f[28] = total; f[29] = eT; f[30] = eR;
   if (loss_hist && step < hp.max_steps) loss_hist[step] = total;
   if (hp.early_stop && step > hp.min_step) {

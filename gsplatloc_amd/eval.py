@@ -49,6 +49,10 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
             print(f"frame {i}: steps {res.steps} loss {res.best_loss:.3e} eT {res.best_eT:.3e} eR {res.best_eR:.3e}")
     dt = time.perf_counter() - t0
     finite = [(a, b) for a, b in zip(eTs, eRs) if math.isfinite(a) and math.isfinite(b)]
+    if not finite:  # e.g. num_iters <= 101: the minimum-loss read-out starts after step 100 and never fired
+        return {"ATE": float("nan"), "AAE": float("nan"), "frames": n, "frames_with_result": 0,
+                "mean_steps": sum(steps) / max(len(steps), 1), "seconds": dt, "frames_per_s": n / dt if dt > 0 else None,
+                "error": "no frame produced a minimum-loss read-out (num_iters must exceed 101)"}
     return {"ATE": rmse([a for a, _ in finite]), "AAE": rmse([b for _, b in finite]), "frames": n,
             "frames_with_result": len(finite), "mean_steps": sum(steps) / max(len(steps), 1),
             "seconds": dt, "frames_per_s": n / dt if dt > 0 else None}

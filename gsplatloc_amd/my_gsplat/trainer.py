@@ -30,10 +30,13 @@ def calculate_translation_error(estimated_pose: Tensor, true_pose: Tensor) -> fl
 
 
 def calculate_rotation_error(estimated_pose: Tensor, true_pose: Tensor) -> float:
-    """eval/utils.py:144-168: rotation angle of R_est R_gt^T in degrees."""
-    Rr = estimated_pose[:3, :3] @ true_pose[:3, :3].T
-    c = torch.clamp((torch.trace(Rr) - 1.0) / 2.0, -1.0, 1.0)
-    return float(torch.acos(c) * 180.0 / math.pi)
+    """eval/utils.py:144-168: rotation angle of R_est R_gt^T in degrees.  The reference takes
+    acos((trace - 1) / 2), which float32 resolves only down to ~0.02 degrees; the same angle from
+    |R_est - R_gt|_F^2 = 8 sin^2(theta / 2) is accurate at the 1e-3 degree level the tracker reaches
+    (same formula as csrc/tracker.hip)."""
+    d = estimated_pose[:3, :3] - true_pose[:3, :3]
+    s = torch.sqrt((d * d).sum() * 0.125).clamp(max=1.0)
+    return float(2.0 * torch.asin(s) * 180.0 / math.pi)
 
 
 @dataclass

@@ -197,25 +197,25 @@ class _CRasterize(torch.autograd.Function):
     enough for BASELINE.json's frame sizes.  Differentiable in the view matrix only -- all the tracker needs."""
 
     @staticmethod
-    def forward(ctx, viewmat, means, quats, scales, opacities, sh, K, W, H, threads):
+    def forward(ctx, viewmat, means, quats, scales, opacities, sh, K, W, H, threads, precision="f64"):
         from . import c_oracle
 
-        ctx.args = (means, quats, scales, opacities, sh, K, W, H, threads)
+        ctx.args = (means, quats, scales, opacities, sh, K, W, H, threads, precision)
         ctx.save_for_backward(viewmat)
         out = c_oracle.rasterization(means, quats, scales, opacities, sh, viewmat, K, W, H, sh_degree=1,
-                                     render_mode="RGB+ED", precision="f64", threads=threads)
-        return torch.from_numpy(out["render"])[None], torch.from_numpy(out["alphas"])[None, ..., None]
+                                     render_mode="RGB+ED", precision=precision, threads=threads)
+        return (torch.from_numpy(out["render"]).double()[None], torch.from_numpy(out["alphas"]).double()[None, ..., None])
 
     @staticmethod
     def backward(ctx, v_render, v_alphas):
         from . import c_oracle
 
-        means, quats, scales, opacities, sh, K, W, H, threads = ctx.args
+        means, quats, scales, opacities, sh, K, W, H, threads, precision = ctx.args
         (viewmat,) = ctx.saved_tensors
         out = c_oracle.rasterization(means, quats, scales, opacities, sh, viewmat, K, W, H, sh_degree=1,
                                      render_mode="RGB+ED", v_render=v_render[0], v_alphas=v_alphas[0, ..., 0],
-                                     precision="f64", threads=threads)
-        return (torch.from_numpy(out["v_viewmat"]),) + (None,) * 9
+                                     precision=precision, threads=threads)
+        return (torch.from_numpy(out["v_viewmat"]).double(),) + (None,) * 10
 
 
 def gs_forward_c(means, quats, scales, opacities, sh, c2w, K, W, H, threads=None):

@@ -246,13 +246,18 @@ def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
     got = ctx.backward(v_render, torch.zeros(H, W, 1, device=dev), full=False)["viewmat"].cpu().double()
     loss_g = float(0.8 * partials.view(-1, 2)[:, 0].sum() + 0.2 * partials.view(-1, 2)[:, 1].sum()) / (W * H)
     # oracle: float64 C rasterizer under autograd + the restated loss
-    Vo = sc["viewmat"].cpu().double().requires_grad_()
     cpu = [sc[k].cpu().double() for k in ("means", "quats", "scales", "opacities", "sh")]
-    renders, _ = T._CRasterize.apply(Vo, *cpu, sc["K"].cpu().double(), W, H, THREADS)
-    total, _, _ = T.tracking_loss(renders[..., 3:4], gt.cpu().double()[None, ..., None])
-    total.backward()
-    err = rel_inf(got[:3], Vo.grad[:3])
-    report(f"tracker-loss pose gradient, {N} Gaussians 640x480", 0.0, loss_rel=abs(loss_g - float(total)) / float(total),
-           v_viewmat=err)
-    assert abs(loss_g - float(total)) < 1e-4 * float(total)
-    assert err < POSE_GRAD_TOL, err
+    grad, total = {}, {}
+    for precision in ("f64", "f32"):  # f32: the float32 floor of this quantity, from the oracle's own float32 build
+        Vo = sc["viewmat"].cpu().double().requires_grad_()
+        renders, _ = T._CRasterize.apply(Vo, *cpu, sc["K"].cpu().double(), W, H, THREADS, precision)
+        total[precision], _, _ = T.tracking_loss(renders[..., 3:4], gt.cpu().double()[None, ..., None])
+        total[precision].backward()
+        grad[precision] = Vo.grad[:3].clone()
+    err, floor32 = rel_inf(got[:3], grad["f64"]), rel_inf(grad["f32"], grad["f64"])
+    report(f"tracker-loss pose gradient, {N} Gaussians 640x480", 0.0,
+           loss_rel=abs(loss_g - float(total["f64"])) / float(total["f64"]), v_viewmat=err, v_viewmat_f32_oracle=floor32)
+    assert abs(loss_g - float(total["f64"])) < 1e-4 * float(total["f64"])
+    # an L1 loss has sign(d - g) in its gradient: where the rendered and the target depth cross, float32 rounding of d
+    # flips the sign of that pixel's term, so the gradient carries a float32 floor well above the loss's own
+    assert err < max(POSE_GRAD_TOL, 2.0 * floor32), (err, floor32)

@@ -1,0 +1,81 @@
+"""GPU: the reference's evaluation protocol end to end on a synthetic Replica-format sequence, through the CLI
+(`python -m gsplatloc_amd.eval`): every frame pair is tracked from the ground-truth pose of frame i
+(/root/reference/src/my_gsplat/gs_trainer_total.py:49-63), at most 2000 iterations, early stop with patience 200
+after step 100 and the error read at the minimum-loss iterate (:160-185), ATE / AAE = RMSE over the frames
+(eval/utils.py:113-119).  The levels asserted are those of the reference's Replica table
+(/root/reference/docs/res.json:20-23: ATE 1.6e-4 .. 2.4e-4 m, AAE ~0.01 deg): ATE <= 2e-4 m, AAE <= 0.01 deg.
+The CPU ICP baseline of BASELINE.json configs[0] runs on the same files and is reported beside it
+(/root/reference/res.json:2-147 has GICP at centimetres on Replica)."""
+import json
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_sequence(root, W, H, n):
+    """Replica layout (results/depthNNNNNN.png at scale 6553.5, frameNNNNNN.jpg, traj.txt, cam_params.json) of a
+    camera drifting through the synthetic room: ~1 cm and ~0.4 deg between frames."""
+    from PIL import Image
+
+    from gsplatloc_amd.synthetic import replica_intrinsics, room_depth
+
+    d = root / "room0" / "results"
+    d.mkdir(parents=True)
+    K = replica_intrinsics(W, H)
+    cam = {"camera": {"w": W, "h": H, "fx": float(K[0, 0]), "fy": float(K[1, 1]), "cx": float(K[0, 2]),
+                      "cy": float(K[1, 2]), "scale": 6553.5}}
+    (root / "cam_params.json").write_text(json.dumps(cam))
+    rng = np.random.default_rng(5)
+    poses = []
+    c2w = np.eye(4)
+    for i in range(n):
+        if i:
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            th = np.radians(0.4)
+            Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+            step = np.eye(4)
+            step[:3, :3] = R
+            t = rng.normal(size=3)
+            step[:3, 3] = 0.01 * t / np.linalg.norm(t)
+            c2w = c2w @ step
+        depth = room_depth(W, H, K, torch.from_numpy(c2w).float()).numpy()
+        Image.fromarray(np.round(depth * 6553.5).astype(np.uint16)).save(d / f"depth{i:06d}.png")
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(d / f"frame{i:06d}.jpg")
+        poses.append(c2w.copy())
+    with open(root / "room0" / "traj.txt", "w") as f:
+        for p in poses:
+            f.write(" ".join(f"{v:.12f}" for v in p.reshape(-1)) + "\n")
+
+
+def test_sequence_ate_with_the_reference_protocol(tmp_path, repo_root):
+    W, H, n = 640, 480, 5
+    _write_sequence(tmp_path, W, H, n)
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, "-m", "gsplatloc_amd.eval", "--dataset", "Replica", "--rooms", "room0", "--root", str(tmp_path),
+           "--num-iters", "2000", "--out", str(out), "--verbose"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=repo_root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    r = json.loads(out.read_text())["room0"]["gsplatloc_amd"]
+    print("[eval] gsplatloc_amd", json.dumps(r))
+    print(res.stdout[-1500:])
+    assert r["frames_with_result"] == r["frames"] == n - 1
+    # the ICP baseline on the same files (CPU)
+    icp_out = tmp_path / "icp.json"
+    icp = subprocess.run([sys.executable, "-m", "gsplatloc_amd.icp_eval", "--dataset", "Replica", "--rooms", "room0", "--root",
+                          str(tmp_path), "--method", "GICP", "--stride", "4", "--out", str(icp_out)], capture_output=True,
+                         text=True, timeout=900, cwd=repo_root)
+    assert icp.returncode == 0, icp.stderr[-3000:]
+    b = json.loads(icp_out.read_text())["room0"]
+    print("[eval] GICP baseline", json.dumps(b))
+    assert r["ATE"] <= 2e-4, r
+    assert r["AAE"] <= 0.01, r
+    # (on this noise-free box room GICP is at its best -- perfect planes, no occlusion -- so the two are only reported
+    #  side by side; the reference's claim against GICP is about real scans, res.json:2-147)
+    assert b["ATE"] < 0.01 and b["frames"] == n
