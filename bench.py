@@ -415,6 +415,24 @@ def main():
         if "nocopy" in diag:       # diagnosis: graph replays of two processes, no copies between them
             if dist is not None:
                 dist.barrier()
+        elif "eagerkernel" in diag:  # diagnosis: an eager kernel launch of the library between two graph replays
+            C.pack_pose_reduce(ctx.v_viewmat, pose_grad)
+        elif "sidestream" in diag:  # diagnosis: the copies on a second stream, ordered with events
+            cur = torch.cuda.current_stream()
+            copy_stream.wait_stream(cur)
+            with torch.cuda.stream(copy_stream):
+                host16.copy_(pose_grad, non_blocking=True)
+            copy_stream.synchronize()
+            if dist is not None:
+                dist.all_reduce(host16)
+            with torch.cuda.stream(copy_stream):
+                pose_grad.copy_(host16, non_blocking=True)
+            cur.wait_stream(copy_stream)
+        elif "d2honly" in diag:
+            host16.copy_(pose_grad, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        elif "h2donly" in diag:
+            pose_grad.copy_(host16, non_blocking=True)
         elif host16 is not None:
             host16.copy_(pose_grad, non_blocking=True)
             torch.cuda.current_stream().synchronize()
@@ -439,9 +457,11 @@ def main():
         trace("graph captured")
     render = graph.replay if graph is not None else render_step
 
+    copy_stream = torch.cuda.Stream() if "sidestream" in diag else None
+
     def run():
         render()
-        if dist is not None or "hostcopy" in diag:
+        if dist is not None or "hostcopy" in diag or "eagerkernel" in diag:
             collective()
 
     for _ in range(args.warmup):

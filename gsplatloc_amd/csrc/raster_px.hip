@@ -67,14 +67,17 @@ __device__ __forceinline__ int compact_quadrants(Stage& sb, int tid, bool valid_
 
 // Per-lane 64-bit candidate mask of one chunk: bit k set <=> candidate k's box covers this lane's pixel.
 // lo/hi are the candidate's inclusive column (row) ranges inside the quadrant (empty if hi < lo).
-// Must be called with all 64 lanes active (wave-uniform control flow): the 8+8 ballots are wave-uniform
-// and are handed to the lanes of column/row v with two exec-masked moves each (no v_cndmask, no VCC).
+// The 8+8 ballots are wave-uniform and are handed to the lanes of column/row v with two exec-masked moves each (no
+// v_cndmask, no VCC).  exec is saved, narrowed to (current exec & lanes) for the two moves and restored, so the
+// helper is correct under any control flow the compiler leaves around it.
 __device__ __forceinline__ void masked_mov2(unsigned& dlo, unsigned& dhi, unsigned long long value,
                                             unsigned long long lanes) {
   unsigned vlo = (unsigned)value, vhi = (unsigned)(value >> 32);
-  asm volatile("s_mov_b64 exec, %4\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_mov_b64 exec, -1"
-               : "+v"(dlo), "+v"(dhi)
-               : "s"(vlo), "s"(vhi), "s"(lanes));
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %2, exec\n\ts_and_b64 exec, %2, %5\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\ts_mov_b64 exec, %2"
+               : "+v"(dlo), "+v"(dhi), "=&s"(saved)
+               : "s"(vlo), "s"(vhi), "s"(lanes)
+               : "scc");
 }
 __device__ __forceinline__ void pixel_masks(int lox, int hix, int loy, int hiy, int lane, unsigned& mlo, unsigned& mhi) {
   unsigned clo = 0, chi = 0, rlo = 0, rhi = 0;

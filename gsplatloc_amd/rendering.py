@@ -86,12 +86,10 @@ def rasterization(
     if sparse_grad:
         raise NotImplementedError("sparse_grad is not supported (GsplatLoc: sparse_grad=False, model.py:122)")
 
-    if sh_degree is None:
-        # treat colors as post-activation values, should be in shape [N, D] or [C, N, D]
+    if sh_degree is None:  # colours are final values: [N, D] shared by the cameras, or [C, N, D]
         assert (colors.dim() == 2 and colors.shape[0] == N) or (
             colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
-    else:
-        # treat colors as SH coefficients, should be in shape [N, K, 3] or [C, N, K, 3]
+    else:  # colours are SH coefficients with K >= (sh_degree + 1)^2 bands: [N, K, 3] or [C, N, K, 3]
         assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
             colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
         assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
@@ -105,88 +103,52 @@ def rasterization(
             radius_clip=radius_clip, antialiased=(rasterize_mode == "antialiased"))
         return render[None], alphas[None], meta
 
-    # General path (several cameras, backgrounds, wide colour channels): stage operators.
-    # Project Gaussians to 2D.
+    # General path (several cameras, a background colour): the stage operators, one after the other.
+    # ``channel_chunk`` is accepted for signature compatibility; the compositing operator takes any channel count.
+    want_depth = render_mode in ("D", "ED", "RGB+D", "RGB+ED")
+    want_rgb = render_mode.startswith("RGB")
     radii, means2d, depths, conics, compensations = fully_fused_projection(
-        means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False,
-        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
-        calc_compensations=(rasterize_mode == "antialiased"),
-    )
-    opacities = opacities.repeat(C, 1)  # [C, N]
-    if compensations is not None:
-        opacities = opacities * compensations
+        means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, packed=False, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, sparse_grad=False,
+        calc_compensations=(rasterize_mode == "antialiased"))
+    opac = opacities[None].expand(C, N)
+    if compensations is not None:  # "antialiased": opacity scaled by sqrt(det Sigma / det(Sigma + eps2d I))
+        opac = opac * compensations
+    opac = opac.contiguous()
+
+    # per-camera features [C, N, D]: RGB (direct, or SH evaluated along the view direction, shifted by 0.5 and
+    # clamped at 0 as the CUDA backends do), then the camera-space depth as the last channel
+    feats = []
+    if want_rgb:
+        if sh_degree is None:
+            rgb = colors if colors.dim() == 3 else colors[None].expand(C, N, colors.shape[-1])
+        else:
+            cam_pos = torch.linalg.inv(viewmats)[:, :3, 3]                      # [C, 3]
+            view_dirs = means[None] - cam_pos[:, None]                          # [C, N, 3]
+            coeffs = colors if colors.dim() == 4 else colors[None].expand(C, *colors.shape)
+            rgb = (spherical_harmonics(sh_degree, view_dirs, coeffs, masks=radii > 0) + 0.5).clamp_min(0.0)
+        feats.append(rgb)
+    if want_depth:
+        feats.append(depths[..., None])
+    feats = torch.cat(feats, dim=-1) if len(feats) > 1 else feats[0]
+    bg = backgrounds
+    if bg is not None and want_depth:  # the depth channel composites over 0
+        bg = torch.cat([bg, bg.new_zeros(C, 1)], dim=-1) if want_rgb else bg.new_zeros(C, 1)
+
+    tile_width, tile_height = -(-width // tile_size), -(-height // tile_size)
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height,
+                                                          packed=False, n_cameras=C)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    render_colors, render_alphas = rasterize_to_pixels(means2d, conics, feats, opac, width, height, tile_size,
+                                                       isect_offsets, flatten_ids, backgrounds=bg)
+    if render_mode in ("ED", "RGB+ED"):  # expected depth: accumulated depth over accumulated alpha
+        expected = render_colors[..., -1:] / render_alphas.clamp(min=1e-10)
+        render_colors = torch.cat([render_colors[..., :-1], expected], dim=-1)
 
     meta.update({
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
-        "conics": conics, "opacities": opacities,
+        "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
+        "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+        "isect_offsets": isect_offsets, "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
     })
-
-    # Turn colors into [C, N, D]
-    if sh_degree is None:
-        if colors.dim() == 2:
-            colors = colors.expand(C, -1, -1)
-    else:
-        camtoworlds = torch.inverse(viewmats)  # [C, 4, 4]
-        dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]  # [C, N, 3]
-        masks = radii > 0  # [C, N]
-        if colors.dim() == 3:
-            shs = colors.expand(C, -1, -1, -1)  # [C, N, K, 3]
-        else:
-            shs = colors
-        colors = spherical_harmonics(sh_degree, dirs, shs, masks=masks)  # [C, N, 3]
-        # make it apple-to-apple with Inria's CUDA Backend.
-        colors = torch.clamp_min(colors + 0.5, 0.0)
-
-    # Rasterize to pixels
-    if render_mode in ["RGB+D", "RGB+ED"]:
-        colors = torch.cat((colors, depths[..., None]), dim=-1)
-        if backgrounds is not None:
-            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
-    elif render_mode in ["D", "ED"]:
-        colors = depths[..., None]
-        if backgrounds is not None:
-            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
-    else:  # RGB
-        pass
-
-    # Identify intersecting tiles
-    tile_width = math.ceil(width / float(tile_size))
-    tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
-        means2d, radii, depths, tile_size, tile_width, tile_height, packed=False, n_cameras=C,
-    )
-    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
-
-    meta.update({
-        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
-        "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "width": width,
-        "height": height, "tile_size": tile_size, "n_cameras": C,
-    })
-
-    if colors.shape[-1] > channel_chunk:
-        # slice into chunks
-        n_chunks = (colors.shape[-1] + channel_chunk - 1) // channel_chunk
-        render_colors, render_alphas = [], []
-        for i in range(n_chunks):
-            colors_chunk = colors[..., i * channel_chunk:(i + 1) * channel_chunk]
-            backgrounds_chunk = (backgrounds[..., i * channel_chunk:(i + 1) * channel_chunk]
-                                 if backgrounds is not None else None)
-            render_colors_, render_alphas_ = rasterize_to_pixels(
-                means2d, conics, colors_chunk, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-                backgrounds=backgrounds_chunk,
-            )
-            render_colors.append(render_colors_)
-            render_alphas.append(render_alphas_)
-        render_colors = torch.cat(render_colors, dim=-1)
-        render_alphas = render_alphas[0]  # discard the rest
-    else:
-        render_colors, render_alphas = rasterize_to_pixels(
-            means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
-            backgrounds=backgrounds,
-        )
-    if render_mode in ["ED", "RGB+ED"]:
-        # normalize the accumulated depth to get the expected depth
-        render_colors = torch.cat(
-            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
-
     return render_colors, render_alphas, meta

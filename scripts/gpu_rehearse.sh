@@ -1,24 +1,22 @@
 #!/usr/bin/env bash
-# Diagnosis of the "write access to a read-only page" fault of graph replay on the N > 1 path (two ranks on ONE
-# GPU, gloo through the host).  Staged from the least to the most complete reproduction; every stage is its own
-# process (pair); the first failure stops the script, so one call can fault at most once.
-#   A: ONE process, strip mode, graph replay + pinned D2H/H2D copies between replays (no second process, no gloo)
-#   B: two processes, graph replays only, dist.barrier() between them (no copies)
-#   C: two processes, the shipped path (graph + pinned copies + gloo all-reduce), HIP API log kept
+# Diagnosis of the "write access to a read-only page" fault: ONE process, graph replay with something else issued on
+# the stream between two replays (stage A of the previous script reproduced it: strip + pinned D2H / H2D copies).
+# Every stage is its own process; the first failure stops the script, so one call faults at most once.
 set -o pipefail
 mkdir -p gpurun_out
 export GSLOC_BENCH_TRACE=1
 B="--steps 12 --warmup 6 --no-cpu-baseline --no-tracker --no-variants"
-finish() {
-  local tag=$1 rc=$2
-  grep -E "Memory access fault|^\{" "gpurun_out/rehearse_${tag}.log" | cut -c1-200
+stage() {
+  local tag=$1; shift
+  timeout -k 10 240 env "$@" python bench.py $B > "gpurun_out/rehearse_${tag}.log" 2>&1
+  local rc=$?
+  grep -E "Memory access fault" "gpurun_out/rehearse_${tag}.log" | cut -c1-200
   echo "stage ${tag}: rc=${rc}"
-  if [ $rc -ne 0 ]; then grep -E "diag rank|trace rank" "gpurun_out/rehearse_${tag}.log" | tail -60; exit $rc; fi
+  if [ $rc -ne 0 ]; then tail -c 400000 "gpurun_out/rehearse_${tag}.log" > "gpurun_out/rehearse_${tag}_tail.log"; rm -f "gpurun_out/rehearse_${tag}.log"; exit $rc; fi
 }
-GSLOC_DIAG=strip,hostcopy timeout -k 10 240 python bench.py $B > gpurun_out/rehearse_A.log 2>&1; finish A $?
-GSLOC_DIAG=nocopy timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-  --master-port 29611 bench.py --gpus 2 --rehearse-on-one-gpu $B > gpurun_out/rehearse_B.log 2>&1; finish B $?
-GSLOC_DIAG=full AMD_LOG_LEVEL=3 timeout -k 10 240 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
-  --master-port 29612 bench.py --gpus 2 --rehearse-on-one-gpu $B > gpurun_out/rehearse_C.log 2>&1
-rc=$?; tail -c 3000000 gpurun_out/rehearse_C.log > gpurun_out/rehearse_C_tail.log; rm -f gpurun_out/rehearse_C.log
-grep -E "Memory access fault|^\{" gpurun_out/rehearse_C_tail.log | cut -c1-200; echo "stage C: rc=$rc"; exit $rc
+stage S1_eager_kernel_between_replays GSLOC_DIAG=strip,eagerkernel
+stage S2_copies_on_side_stream GSLOC_DIAG=strip,hostcopy,sidestream
+stage S3_host_kernarg GSLOC_DIAG=strip,hostcopy HIP_FORCE_DEV_KERNARG=0
+stage S4_d2h_only GSLOC_DIAG=strip,hostcopy,d2honly
+stage S5_h2d_only GSLOC_DIAG=strip,hostcopy,h2donly
+stage S6_full_frame_copies_logged GSLOC_DIAG=hostcopy AMD_LOG_LEVEL=3
