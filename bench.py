@@ -368,14 +368,13 @@ def main():
     # ---- tile-row strip of this rank (balanced on a calibration pass) -------------------------
     rows = (0, th)
     n_local = N
-    diag = os.environ.get("GSLOC_DIAG", "")  # diagnosis of the N > 1 graph-replay fault (scripts/gpu_rehearse.sh)
-    if world > 1 or "strip" in diag:
+    if world > 1:
         # once per frame (untimed): balance strips on a full binning pass, keep the Gaussians that can reach
         # this rank's strip (1-tile guard band), the rest never touch its pixels
         from gsplatloc_amd.parallel import gaussians_for_strip
         cal = C.RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
         cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
-        rows = strip_rows(cal.offs, cal.tw, cal.th, max(world, 2))[rank]
+        rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank]
         idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
         for k in sc:
             sc[k] = sc[k][idx].contiguous()
@@ -393,51 +392,24 @@ def main():
     v_alphas = torch.zeros(H, W, 1, device=dev)
     pose_grad = torch.zeros(16, device=dev)  # this rank's 16 floats of the all-reduce
     host16 = None
-    if (dist is not None and args.rehearse_on_one_gpu) or "hostcopy" in diag:
+    if dist is not None and args.rehearse_on_one_gpu:
         host16 = torch.zeros(16).pin_memory()
-    if diag:
-        for name, t in list(vars(ctx).items()) + [("pose_grad", pose_grad), ("host16", host16), ("v_render", v_render)]:
-            if torch.is_tensor(t):
-                print(f"[diag rank {rank}] {name:12s} {t.data_ptr():#x} .. {t.data_ptr() + t.numel() * t.element_size():#x}",
-                      file=sys.stderr, flush=True)
     args_in = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
 
     def render_step():
         """The rank's launches of one step: library kernels and memsets only (captured as one HIP graph)."""
         ctx.forward(*args_in)
         grads = ctx.backward(v_render, v_alphas, full=full)
-        if dist is not None or diag:  # pack the 12 pose-gradient entries (+4 spare) into the all-reduce buffer
+        if dist is not None:  # pack the 12 pose-gradient entries (+4 spare) into the all-reduce buffer
             C.pack_pose_reduce(grads["viewmat"], pose_grad)
 
     def collective():
         """THE collective of the path: one all-reduce of 16 floats (RCCL on the device buffer; the one-GPU
         rehearsal's gloo group goes through a pinned host buffer)."""
-        if "nocopy" in diag:       # diagnosis: graph replays of two processes, no copies between them
-            if dist is not None:
-                dist.barrier()
-        elif "eagerkernel" in diag:  # diagnosis: an eager kernel launch of the library between two graph replays
-            C.pack_pose_reduce(ctx.v_viewmat, pose_grad)
-        elif "sidestream" in diag:  # diagnosis: the copies on a second stream, ordered with events
-            cur = torch.cuda.current_stream()
-            copy_stream.wait_stream(cur)
-            with torch.cuda.stream(copy_stream):
-                host16.copy_(pose_grad, non_blocking=True)
-            copy_stream.synchronize()
-            if dist is not None:
-                dist.all_reduce(host16)
-            with torch.cuda.stream(copy_stream):
-                pose_grad.copy_(host16, non_blocking=True)
-            cur.wait_stream(copy_stream)
-        elif "d2honly" in diag:
+        if host16 is not None:
             host16.copy_(pose_grad, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-        elif "h2donly" in diag:
-            pose_grad.copy_(host16, non_blocking=True)
-        elif host16 is not None:
-            host16.copy_(pose_grad, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            if dist is not None:
-                dist.all_reduce(host16)
+            dist.all_reduce(host16)
             pose_grad.copy_(host16, non_blocking=True)
         else:
             dist.all_reduce(pose_grad)
@@ -457,11 +429,9 @@ def main():
         trace("graph captured")
     render = graph.replay if graph is not None else render_step
 
-    copy_stream = torch.cuda.Stream() if "sidestream" in diag else None
-
     def run():
         render()
-        if dist is not None or "hostcopy" in diag or "eagerkernel" in diag:
+        if dist is not None:
             collective()
 
     for _ in range(args.warmup):

@@ -418,7 +418,7 @@ extern "C" int gsl_isect_count(const float* means2d, const int32_t* radii, int N
   hipStream_t st = (hipStream_t)stream;
   int32_t* counts = (int32_t*)ws;
   int32_t* cursors = counts + n_tiles;
-  if (hipMemsetAsync(counts, 0, (size_t)n_tiles * sizeof(int32_t), st) != hipSuccess) return GSL_ERR_HIP;
+  if (gsl::zero_u32(counts, (size_t)n_tiles, st) != GSL_OK) return GSL_ERR_HIP;
   if (N > 0) {
     int nst = (ty1 - ty0) * tile_w;
     if (nst > 0 && nst <= GSL_HIST_LDS_TILES) {

@@ -785,7 +785,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
   hipStream_t st = (hipStream_t)stream;
   int32_t* counts = (int32_t*)ws;
   int32_t* cursors = counts + n_tiles;
-  if (hipMemsetAsync(counts, 0, (size_t)n_tiles * sizeof(int32_t), st) != hipSuccess) return GSL_ERR_HIP;
+  if (gsl::zero_u32(counts, (size_t)n_tiles, st) != GSL_OK) return GSL_ERR_HIP;
   if (N > 0) {
     dim3 grid((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), block(GSL_F_BIN_THREADS);
     size_t lds = (size_t)(nst > 0 ? nst : 1) * sizeof(int);
@@ -882,7 +882,7 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
   if (antialiased && !compensations) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
-    if (v_viewmat && hipMemsetAsync(v_viewmat, 0, 16 * sizeof(float), st) != hipSuccess) return GSL_ERR_HIP;
+    if (v_viewmat && gsl::zero_u32(v_viewmat, 16, st) != GSL_OK) return GSL_ERR_HIP;
     return GSL_OK;
   }
   if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !Q1 || !vacc) return GSL_ERR_BAD_ARG;

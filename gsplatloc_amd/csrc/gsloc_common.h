@@ -18,6 +18,9 @@
 
 namespace gsl {
 
+// misc.hip: zero n dwords with a kernel of the library (never hipMemsetAsync: see the note there)
+int zero_u32(void* p, size_t n_dwords, hipStream_t st);
+
 struct M3 {  // row-major 3x3
   float m[9];
   __device__ __forceinline__ float& operator()(int r, int c) { return m[r * 3 + c]; }

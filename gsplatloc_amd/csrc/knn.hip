@@ -134,7 +134,7 @@ extern "C" int gsl_knn_count(const float* points, int N, const float* bbox, void
   int32_t* counts = (int32_t*)ws;
   int32_t* cell_of = counts + 2 * cells;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(counts, 0, cells * 2 * sizeof(int32_t), st) != hipSuccess) return GSL_ERR_HIP;
+  if (gsl::zero_u32(counts, (size_t)cells * 2, st) != GSL_OK) return GSL_ERR_HIP;
   if (N == 0) return GSL_OK;
   if (!points) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_knn_count, dim3((N + 255) / 256), dim3(256), 0, st, points, N, bbox, cell_of, counts);

@@ -12,3 +12,19 @@ extern "C" const char* gsl_status_string(int status) {
     default: return "unknown status";
   }
 }
+
+// Zeroing of scratch arrays by a kernel of the library instead of hipMemsetAsync: a captured call sequence then
+// holds kernel nodes only.  (A memset node in a captured iteration made ROCm 7.2 fault -- "write access to a
+// read-only page" -- as soon as anything else was issued on the stream between two replays)
+namespace gsl {
+__global__ __launch_bounds__(256) void k_zero_u32(uint32_t* __restrict__ p, size_t n) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+int zero_u32(void* p, size_t n_dwords, hipStream_t st) {
+  if (n_dwords == 0) return GSL_OK;
+  hipLaunchKernelGGL(k_zero_u32, dim3((unsigned)((n_dwords + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, n_dwords);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+}  // namespace gsl

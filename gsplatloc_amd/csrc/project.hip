@@ -176,7 +176,7 @@ extern "C" int gsl_project_bwd(const float* means, const float* quats, const flo
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
     if (v_viewmat) {
-      if (hipMemsetAsync(v_viewmat, 0, 16 * sizeof(float), st) != hipSuccess) return GSL_ERR_HIP;
+      if (gsl::zero_u32(v_viewmat, 16, st) != GSL_OK) return GSL_ERR_HIP;
     }
     return GSL_OK;
   }

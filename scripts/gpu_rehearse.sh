@@ -1,22 +1,9 @@
 #!/usr/bin/env bash
-# Diagnosis of the "write access to a read-only page" fault: ONE process, graph replay with something else issued on
-# the stream between two replays (stage A of the previous script reproduced it: strip + pinned D2H / H2D copies).
-# Every stage is its own process; the first failure stops the script, so one call faults at most once.
+# Rehearsal of the N > 1 path of bench.py on ONE GPU: two ranks, each replays its HIP graph per step, the 16-float
+# all-reduce goes through gloo and a pinned host buffer.  (Round 1's "write access to a read-only page" fault of this
+# path came from the hipMemsetAsync node inside the captured iteration)
 set -o pipefail
 mkdir -p gpurun_out
-export GSLOC_BENCH_TRACE=1
-B="--steps 12 --warmup 6 --no-cpu-baseline --no-tracker --no-variants"
-stage() {
-  local tag=$1; shift
-  timeout -k 10 240 env "$@" python bench.py $B > "gpurun_out/rehearse_${tag}.log" 2>&1
-  local rc=$?
-  grep -E "Memory access fault" "gpurun_out/rehearse_${tag}.log" | cut -c1-200
-  echo "stage ${tag}: rc=${rc}"
-  if [ $rc -ne 0 ]; then tail -c 400000 "gpurun_out/rehearse_${tag}.log" > "gpurun_out/rehearse_${tag}_tail.log"; rm -f "gpurun_out/rehearse_${tag}.log"; exit $rc; fi
-}
-stage S1_eager_kernel_between_replays GSLOC_DIAG=strip,eagerkernel
-stage S2_copies_on_side_stream GSLOC_DIAG=strip,hostcopy,sidestream
-stage S3_host_kernarg GSLOC_DIAG=strip,hostcopy HIP_FORCE_DEV_KERNARG=0
-stage S4_d2h_only GSLOC_DIAG=strip,hostcopy,d2honly
-stage S5_h2d_only GSLOC_DIAG=strip,hostcopy,h2donly
-stage S6_full_frame_copies_logged GSLOC_DIAG=hostcopy AMD_LOG_LEVEL=3
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 \
+  bench.py --gpus 2 --rehearse-on-one-gpu --steps 20 --warmup 5 > gpurun_out/rehearse_2ranks.log 2>&1
+rc=$?; grep -E "Memory access fault|^\{" gpurun_out/rehearse_2ranks.log | cut -c1-400; echo "two ranks: rc=$rc"; exit $rc
