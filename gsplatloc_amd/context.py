@@ -30,7 +30,7 @@ class RenderContext:
                  K_sh: int = 4, device="cuda", eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10,
                  radius_clip: float = 0.0, antialiased: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
                  capacity: Optional[int] = None, full_grads: bool = True,
-                 pixel_rows: Optional[Tuple[int, int]] = None, staging: str = "fp32"):
+                 pixel_rows: Optional[Tuple[int, int]] = None, staging: str = "fp32", deterministic: bool = False):
         self.lib = load_library()
         self.N, self.W, self.H = int(N), int(width), int(height)
         self.mode = render_mode
@@ -61,6 +61,10 @@ class RenderContext:
         assert staging in ("fp32", "fp16"), staging
         self.staging = staging
         self.Qh = torch.zeros(N, 8, dtype=i32, device=dev) if staging == "fp16" else None
+        # deterministic=True: no float atomics anywhere in the backward (one gradient row per intersection, summed in a
+        # fixed order): bit-identical gradients from run to run, at the price of a slower backward
+        self.deterministic = bool(deterministic)
+        self.vrow = None
         self.comps = torch.zeros(N, dtype=f32, device=dev) if self.antialiased else None
         self.offs = torch.zeros(self.n_tiles + 1, dtype=i32, device=dev)
         self.n_is = torch.zeros(1, dtype=i32, device=dev)
@@ -97,6 +101,8 @@ class RenderContext:
         self.capacity = max(int(capacity), 1)
         self.keys = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
         self.flatten_ids = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
+        if self.deterministic:
+            self.vrow = torch.zeros(self.capacity, 16, dtype=torch.float32, device=self.device)
 
     def calibrate(self, means, quats, scales, opacities, colors, viewmat, K, headroom: float = 1.3) -> int:
         """One synchronising projection pass to size the intersection buffers."""
@@ -151,8 +157,8 @@ class RenderContext:
     def _bin(self) -> None:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
-                                     ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, current_stream()),
-              "gsl_fused_bin")
+                                     ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, int(self.deterministic),
+                                     current_stream()), "gsl_fused_bin")
 
     def _raster_fwd(self) -> None:
         check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
@@ -173,10 +179,15 @@ class RenderContext:
                   "gsl_tiny_gather")
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
-                                                current_stream()), "gsl_fused_raster_bwd")
+                                                ptr(self.vrow), current_stream()), "gsl_fused_raster_bwd")
 
     def _project_bwd(self, full: bool) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
+        if self.vrow is not None and not self.tiny:  # deterministic general backward: rows per intersection
+            det = (ptr(self.vrow), ptr(self.keys), ptr(self.offs), ptr(self.Q0), self.tw, self.th, self.ty0, self.ty1,
+                   self.capacity)
+        else:  # (the tiny-splat backward has no atomics to begin with)
+            det = (None, None, None, None, 0, 0, 0, 0, 0)
         check(self.lib.gsl_fused_project_bwd(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
@@ -184,7 +195,7 @@ class RenderContext:
             ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
             ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
             ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
-            self.n_tiles, current_stream()), "gsl_fused_project_bwd")
+            self.n_tiles, *det, current_stream()), "gsl_fused_project_bwd")
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],

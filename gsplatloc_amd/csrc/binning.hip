@@ -319,7 +319,8 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
 __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ tile_offsets, int tile_begin,
                                                    long long capacity, uint64_t* __restrict__ keys,
                                                    int32_t* __restrict__ flatten_ids,
-                                                   int64_t* __restrict__ isect_ids, int64_t cam_enc) {
+                                                   int64_t* __restrict__ isect_ids, int64_t cam_enc,
+                                                   int write_sorted_keys) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
   int t = tile_begin + blockIdx.x;
   long long s = tile_offsets[t], e = tile_offsets[t + 1];
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
       uint64_t k = skeys[i];
       flatten_ids[s + i] = (int32_t)(uint32_t)k;
       if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
+      if (write_sorted_keys) src[i] = k;  // (depth bits, id) in list order: the deterministic backward searches them
     }
   } else {
     __syncthreads();
@@ -471,7 +473,20 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc);
+                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, 0);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+// gsl_tile_sort that can also leave the sorted (depth bits, id) keys in sort_keys (internal: gsl_fused_bin)
+extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+                                  uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
+                                  int write_sorted_keys, void* stream) {
+  if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
+  if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
+  if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, write_sorted_keys);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -280,26 +280,27 @@ typedef float gsl_f32x4 __attribute__((ext_vector_type(4)));
 #define GSL_MB 192        // list entries staged per batch (three 64-entry chunks)
 #define GSL_MPITCH 72     // floats per tile row: 16-byte reads of lane (k, i) at [i][16 m + 4 k] hit 16 distinct bank quads
 
-template <int D>
+template <int D, bool DET = false>
 struct FStageM {
   static constexpr int A = 6 + D;   // moment / gradient row: [6 geometric][D colour]
   static constexpr int AP = A | 1;  // odd LDS pitch
+  static constexpr int NW = DET ? 4 : 1;  // deterministic mode: one moment row per (wave, slot), summed in wave order
   float4 s0[GSL_MB];
   float4 s1[GSL_MB];
   float4 s2[(D >= 3) ? GSL_MB : 1];
   int32_t id[GSL_MB];
-  float acc[GSL_MB * AP];             // per-slot moments, converted in place to the gradient row at flush
+  float acc[NW * GSL_MB * AP];        // per-slot moments, converted in place to the gradient row at flush
   float tile[4][16 * GSL_MPITCH];     // per wave: rows 0-7 = w of the group's splats, rows 8-15 = f
   int32_t gslot[4][8];                // batch slot of each splat of the group
   uint16_t list[4][64];
 };
 
-template <int D, int CG>
-__device__ __forceinline__ void mraster_group_flush(FStageM<D>& sb, int wv, int lane, int count,
+template <int D, int CG, bool DET>
+__device__ __forceinline__ void mraster_group_flush(FStageM<D, DET>& sb, int wv, int lane, int count,
                                                     const float (&bmat)[16]) {
   // D[i][j] = sum_k A[i][k] B[k][j]; lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; K-step kb
   // of lane-row k is pixel 16 (kb >> 2) + 4 k + (kb & 3); result row 4 (l >> 4) + r, column l & 15 in register r.
-  constexpr int AP = FStageM<D>::AP;
+  constexpr int AP = FStageM<D, DET>::AP;
   int k = lane >> 4, ij = lane & 15;
   const float* row = &sb.tile[wv][ij * GSL_MPITCH + 4 * k];
   gsl_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -327,19 +328,24 @@ __device__ __forceinline__ void mraster_group_flush(FStageM<D>& sb, int wv, int 
   int sl[4] = {gs.x, gs.y, gs.z, gs.w};
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    if (col_ok && sbase + r < count && d[r] != 0.f) atomicAdd(&sb.acc[sl[r] * AP + col], d[r]);
+    if (col_ok && sbase + r < count && d[r] != 0.f) {
+      // a wave visits a slot once per batch: in deterministic mode its row is a plain store into the wave's own copy
+      if (DET) sb.acc[(wv * GSL_MB + sl[r]) * AP + col] = d[r];
+      else atomicAdd(&sb.acc[sl[r] * AP + col], d[r]);
+    }
 }
 
-template <int D, int CG>
+template <int D, int CG, bool DET>
 __device__ __forceinline__ void mraster_bwd_body(
-    FStageM<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
+    FStageM<D, DET>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
     const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs,
     long long re, int nb, int tid, float px, float py, float qcx, float qcy, float tcx, float tcy, bool inside,
     int bin_final, int wave_final, float T_final, const float (&vc)[D], float va) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
-  constexpr int A = FStageM<D>::A;
-  constexpr int AP = FStageM<D>::AP;
+  constexpr int A = FStageM<D, DET>::A;
+  constexpr int AP = FStageM<D, DET>::AP;
+  constexpr int NW = FStageM<D, DET>::NW;
   int lane = tid & 63, wv = tid >> 6;
   float T = T_final;
   float Bp = -T_final * va;
@@ -410,7 +416,9 @@ __device__ __forceinline__ void mraster_bwd_body(
     }
     if (tid < GSL_MB) {
 #pragma unroll
-      for (int k = 0; k < A; ++k) sb.acc[tid * AP + k] = 0.f;
+      for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int k = 0; k < A; ++k) sb.acc[(w * GSL_MB + tid) * AP + k] = 0.f;
     }
     __syncthreads();
     if (b + 1 < nb) gather(b + 1);
@@ -474,7 +482,7 @@ __device__ __forceinline__ void mraster_bwd_body(
           if (++hh == 8) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            mraster_group_flush<D, CG>(sb, wv, lane, 8, bmat);
+            mraster_group_flush<D, CG, DET>(sb, wv, lane, 8, bmat);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             hh = 0;
@@ -489,21 +497,25 @@ __device__ __forceinline__ void mraster_bwd_body(
     if (hh) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      mraster_group_flush<D, CG>(sb, wv, lane, hh, bmat);
+      mraster_group_flush<D, CG, DET>(sb, wv, lane, hh, bmat);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // Moments -> gradient row (one thread per slot), then pack non-zero slots so that 16 consecutive lanes add one
-    // Gaussian's 64-byte row.
+    // Moments -> gradient row (one thread per slot).
     {
       bool nz = false;
+      float mo[A];
+#pragma unroll
+      for (int k = 0; k < A; ++k) mo[k] = 0.f;
       if (tid < bsize) {
-        float mo[A];
 #pragma unroll
         for (int k = 0; k < A; ++k) {
-          mo[k] = sb.acc[tid * AP + k];
-          nz = nz || (mo[k] != 0.f);
+          float m = sb.acc[tid * AP + k];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) m += sb.acc[(w * GSL_MB + tid) * AP + k];  // fixed wave order
+          mo[k] = m;
+          nz = nz || (m != 0.f);
         }
         if (nz) {
           float4 q0 = sb.s0[tid], q1 = sb.s1[tid];
@@ -513,39 +525,59 @@ __device__ __forceinline__ void mraster_bwd_body(
           float Sxy = X * (Y * S - mo[2]) - Y * mo[1] + mo[4];
           float Syy = Y * (Y * S - 2.f * mo[2]) + mo[5];
           float no = -q0.w;  // v_sigma = -opacity * w
-          sb.acc[tid * AP + 0] = no * (q1.x * Sx + q1.y * Sy);
-          sb.acc[tid * AP + 1] = no * (q1.y * Sx + q1.z * Sy);
-          sb.acc[tid * AP + 2] = 0.5f * no * Sxx;
-          sb.acc[tid * AP + 3] = no * Sxy;
-          sb.acc[tid * AP + 4] = 0.5f * no * Syy;
-          sb.acc[tid * AP + 5] = S;
+          mo[0] = no * (q1.x * Sx + q1.y * Sy);
+          mo[1] = no * (q1.y * Sx + q1.z * Sy);
+          mo[2] = 0.5f * no * Sxx;
+          mo[3] = no * Sxy;
+          mo[4] = 0.5f * no * Syy;
+          mo[5] = S;
+          if (!DET) {  // the packed flush below reads the rows from LDS
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sb.acc[tid * AP + k] = mo[k];
+          }
         }
       }
-      unsigned long long mask = __ballot(nz);
-      int cnt = __popcll(mask);
-      if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
-      __syncthreads();
-      int f = lane & 15;
-      for (int i0 = 0; i0 < cnt; i0 += 4) {
-        int gi = i0 + (lane >> 4);
-        if (gi < cnt && f < A) {
-          int sl = sb.list[wv][gi];
-          size_t g = (size_t)sb.id[sl];
-          atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+      if (DET) {
+        // deterministic mode: the (tile, splat) row goes to the intersection's own slot with plain stores (zero rows
+        // included); the projection backward sums a Gaussian's rows in tile order
+        if (tid < bsize) {
+          float pad[12];
+#pragma unroll
+          for (int k = 0; k < 12; ++k) pad[k] = (k < A && nz) ? mo[k] : 0.f;
+          float4* dst = reinterpret_cast<float4*>(vacc) + 4 * (size_t)(bend - tid);
+          dst[0] = make_float4(pad[0], pad[1], pad[2], pad[3]);
+          dst[1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
+          dst[2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
+        }
+      } else {
+        // pack non-zero slots so that 16 consecutive lanes add one Gaussian's 64-byte row
+        unsigned long long mask = __ballot(nz);
+        int cnt = __popcll(mask);
+        if (nz) sb.list[wv][__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+        __syncthreads();
+        int f = lane & 15;
+        for (int i0 = 0; i0 < cnt; i0 += 4) {
+          int gi = i0 + (lane >> 4);
+          if (gi < cnt && f < A) {
+            int sl = sb.list[wv][gi];
+            size_t g = (size_t)sb.id[sl];
+            atomicAdd(&vacc[g * 16 + f], sb.acc[sl * AP + f]);
+          }
         }
       }
     }
   }
 }
 
-template <int D, bool ED>
+template <int D, bool ED, bool DET>
 __global__ __launch_bounds__(256) void k_mraster_bwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh) {
-  __shared__ FStageM<D> sb;
+  // DET: vacc is vrow[capacity][16], one row per intersection; otherwise vacc[N][16], one row per Gaussian (atomics)
+  __shared__ FStageM<D, DET> sb;
   __shared__ int s_final[4];
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
@@ -583,14 +615,20 @@ __global__ __launch_bounds__(256) void k_mraster_bwd(
   if (D == 4) rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
   int any_rgb = __syncthreads_or(rgb_grad);
   int block_final = max(max(s_final[0], s_final[1]), max(s_final[2], s_final[3]));
+  // nothing behind block_final was composited by any pixel of the tile: start there
+  long long re_all = re;
   if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
+  if (DET) {  // rows of the entries that are not walked are zero
+    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long q = 4 * re + tid; q < 4 * re_all; q += 256) reinterpret_cast<float4*>(vacc)[q] = z;
+  }
   if (rs >= re) return;
   int nb = (int)((re - rs + GSL_MB - 1) / GSL_MB);
   if (D == 4 && !any_rgb)
-    mraster_bwd_body<D, 1>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
+    mraster_bwd_body<D, 1, DET>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
                            bin_final, wave_final, T_final, vc, va);
   else
-    mraster_bwd_body<D, D>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
+    mraster_bwd_body<D, D, DET>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, nb, tid, px, py, qcx, qcy, tcx, tcy, inside,
                            bin_final, wave_final, T_final, vc, va);
 }
 
@@ -606,7 +644,9 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
     const int32_t* __restrict__ radii, const float4* __restrict__ Q1, const float* __restrict__ comps,
     float4* __restrict__ vacc, float* __restrict__ v_means, float* __restrict__ v_quats,
     float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, const float4* __restrict__ vrow, const uint64_t* __restrict__ skeys,
+    const int32_t* __restrict__ tile_offsets, const float4* __restrict__ Q0, int tile_w, int tile_h, int ty0, int ty1,
+    long long capacity) {
   constexpr bool RGB = D >= 3;
   int i = blockIdx.x * 256 + threadIdx.x;
   Cam cam = load_cam(V, Kmat);
@@ -619,9 +659,37 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
   bool live = (i < N) && (radii[i] > 0);
   bool sh_live = false;
   if (live) {
-    float4 r0 = vacc[4 * (size_t)i], r1 = vacc[4 * (size_t)i + 1], r2 = vacc[4 * (size_t)i + 2];
+    float4 r0, r1, r2;
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    vacc[4 * (size_t)i] = z; vacc[4 * (size_t)i + 1] = z; vacc[4 * (size_t)i + 2] = z;
+    if (vrow) {
+      // deterministic mode: the Gaussian's rows were stored per intersection; find its entry in each tile list of
+      // its rectangle (the lists are sorted by (depth bits, id): binary search) and add the rows in tile order
+      r0 = r1 = r2 = z;
+      float4 q0 = GSL_Q(Q0, i);
+      int xmin, ymin, xmax, ymax;
+      tile_rect(q0.x, q0.y, radii[i], 16, tile_w, tile_h, xmin, ymin, xmax, ymax);
+      ymin = max(ymin, ty0);
+      ymax = min(ymax, ty1);
+      uint64_t want = ((uint64_t)__float_as_uint(q0.z) << 32) | (uint32_t)i;
+      for (int y = ymin; y < ymax; ++y)
+        for (int x = xmin; x < xmax; ++x) {
+          long long lo = tile_offsets[y * tile_w + x], hi = tile_offsets[y * tile_w + x + 1];
+          if (hi > capacity) hi = capacity;
+          while (lo < hi) {
+            long long mid = (lo + hi) >> 1;
+            if (skeys[mid] < want) lo = mid + 1; else hi = mid;
+          }
+          if (lo < capacity && skeys[lo] == want) {
+            float4 a = vrow[4 * lo], b = vrow[4 * lo + 1], c = vrow[4 * lo + 2];
+            r0.x += a.x; r0.y += a.y; r0.z += a.z; r0.w += a.w;
+            r1.x += b.x; r1.y += b.y; r1.z += b.z; r1.w += b.w;
+            r2.x += c.x; r2.y += c.y; r2.z += c.z; r2.w += c.w;
+          }
+        }
+    } else {
+      r0 = vacc[4 * (size_t)i]; r1 = vacc[4 * (size_t)i + 1]; r2 = vacc[4 * (size_t)i + 2];
+      vacc[4 * (size_t)i] = z; vacc[4 * (size_t)i + 1] = z; vacc[4 * (size_t)i + 2] = z;
+    }
     // row = [vx vy | va vb vc | vop | col0 col1 col2 col3 ...]
     float vm2x = r0.x, vm2y = r0.y, v_ca = r0.z, v_cb = r0.w, v_cc = r1.x, vop_eff = r1.y;
     float col[4] = {r1.z, r1.w, r2.x, r2.y};
@@ -807,13 +875,14 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
 }
 
 // defined in binning.hip
-extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
-                             uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
-                             void* stream);
+extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+                                  uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
+                                  int write_sorted_keys, void* stream);
 
 extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0, int ty1,
                              int tile_n_bits, const int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
-                             int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes, void* stream) {
+                             int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes,
+                             int write_sorted_keys, void* stream) {
   if (N < 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0)
     return GSL_ERR_BAD_ARG;
   int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
@@ -827,7 +896,8 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
                      (size_t)2 * nst * sizeof(int), st, (const float4*)Q0, radii, N, tile_w, tile_h, ty0, ty1,
                      tile_offsets, cursors, (long long)capacity, sort_keys);
   GSL_CHECK_LAUNCH();
-  return gsl_tile_sort(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0, stream);
+  return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
+                            write_sorted_keys, stream);
 }
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
@@ -843,7 +913,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                    const float* render, const float* alphas, const int32_t* last_ids,
                                    const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                                   const void* Qh, void* stream) {
+                                   const void* Qh, float* vrow, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -851,12 +921,23 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (capacity == 0 || ty0 == ty1 || row0 == row1) return GSL_OK;
-  if (!flatten_ids || !vacc) return GSL_ERR_BAD_ARG;
+  if (!flatten_ids || (!vacc && !vrow)) return GSL_ERR_BAD_ARG;
   if (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
+  if (vrow) {  // deterministic mode: one row per intersection, plain stores, no atomics anywhere
+#define CALL_MD(DD, EE)                                                                                       \
+  hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, true>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,    \
+                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vrow,    \
+                     row0, row1, (const uint4*)Qh)
+    GSL_F_DISPATCH(channels, ed, CALL_MD)
+#undef CALL_MD
+    GSL_CHECK_LAUNCH();
+    return GSL_OK;
+  }
 #define CALL_MB(DD, EE)                                                                                       \
-  hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+  hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, false>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,   \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,    \
                      row0, row1, (const uint4*)Qh)
@@ -872,7 +953,9 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
                                      float eps2d, int antialiased, int channels, const int32_t* radii,
                                      const float* Q1, const float* compensations, float* vacc, float* v_means,
                                      float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
-                                     float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream) {
+                                     float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
+                                     const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0,
+                                     int tile_w, int tile_h, int ty0, int ty1, int64_t capacity, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || n_tiles <= 0) return GSL_ERR_BAD_ARG;
   if (channels != 1 && channels != 3 && channels != 4) return GSL_ERR_BAD_ARG;
   bool full = v_means != nullptr;
@@ -885,7 +968,11 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     if (v_viewmat && gsl::zero_u32(v_viewmat, 16, st) != GSL_OK) return GSL_ERR_HIP;
     return GSL_OK;
   }
-  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !Q1 || !vacc) return GSL_ERR_BAD_ARG;
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !Q1) return GSL_ERR_BAD_ARG;
+  if (!vrow && !vacc) return GSL_ERR_BAD_ARG;
+  if (vrow && (!sorted_keys || !tile_offsets || !Q0 || tile_w <= 0 || tile_h <= 0 || tile_w * tile_h != n_tiles ||
+               ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0))
+    return GSL_ERR_BAD_ARG;
   if (channels >= 3 && !colors) return GSL_ERR_BAD_ARG;
   if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
   float* partials = v_viewmat ? (float*)((int32_t*)ws + 2 * (size_t)n_tiles) : nullptr;
@@ -894,7 +981,8 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
   hipLaunchKernelGGL((gsl::k_fproject_bwd<FF, DD>), dim3(grid), dim3(256), 0, st, means, quats, scales, opacities, \
                      colors, sh_degree, K_sh, viewmat, K, N, width, height, eps2d, antialiased, radii,             \
                      (const float4*)Q1, compensations, (float4*)vacc, v_means, v_quats, v_scales, v_opacities,    \
-                     v_colors, partials)
+                     v_colors, partials, (const float4*)vrow, sorted_keys, tile_offsets, (const float4*)Q0, tile_w,   \
+                     tile_h, ty0, ty1, (long long)capacity)
   if (full) {
     if (channels == 1) CALL_PB(true, 1); else if (channels == 3) CALL_PB(true, 3); else CALL_PB(true, 4);
   } else {

@@ -69,7 +69,7 @@ class _FusedRasterization(torch.autograd.Function):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
         check(lib.gsl_fused_bin(ptr(Q0), ptr(radii), N, tw, th, ty0, ty1, tile_n_bits(n_tiles), ptr(offs), n_isects,
                                 ptr(keys), ptr(flatten_ids) if n_isects else None,
-                                ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, st),
+                                ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, 0, st),
               "gsl_fused_bin")
         render = torch.zeros(H, W, D, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, D, dtype=f32, device=dev)
@@ -114,7 +114,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(vacc), 0, H, None, st), "gsl_fused_raster_bwd")
+                                       ptr(vacc), 0, H, None, None, st), "gsl_fused_raster_bwd")
         ni = ctx.needs_input_grad
         full = any(ni[:5])
         v_means = v_quats = v_scales = v_opac = v_colors = None
@@ -131,7 +131,8 @@ class _FusedRasterization(torch.autograd.Function):
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rgb else None, sh_degree, ctx.K_sh,
             ptr(viewmat), ptr(K), N, W, H, eps2d, int(antialiased), D, ptr(radii), ptr(Q1),
             ptr(comps) if antialiased else None, ptr(vacc), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opac),
-            ptr(v_colors), ptr(v_viewmat), ptr(ws), ws_bytes, n_tiles, st), "gsl_fused_project_bwd")
+            ptr(v_colors), ptr(v_viewmat), ptr(ws), ws_bytes, n_tiles, None, None, None, None, 0, 0, 0, 0, 0, st),
+            "gsl_fused_project_bwd")
         return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
                 v_opac if ni[3] else None, v_colors if (ni[4] and rgb) else None, v_viewmat, None, None, None)
 

@@ -164,6 +164,13 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     then be NULL there).  Transmittance and every accumulator stay float32 (BASELINE.json
  *                     configs[4] "fp16 compositing").  Binning and gsl_fused_project_bwd keep reading
  *                     the float32 records, so the list order is the float32 order.
+ * Deterministic mode (vrow, may be NULL): by default the backward accumulates with float atomics (LDS across the
+ *                     four waves of a tile, memory across the tiles of a Gaussian), whose order varies from run to
+ *                     run.  With write_sorted_keys = 1 in gsl_fused_bin (sort_keys then holds the sorted
+ *                     (depth bits << 32 | id) keys) and vrow[capacity][16] given to gsl_fused_raster_bwd (vacc may be
+ *                     NULL) and gsl_fused_project_bwd (with sorted_keys, tile_offsets, Q0 and the strip), every sum
+ *                     has a fixed order: waves in wave order, a Gaussian's tiles in tile order (its entry in a tile
+ *                     list is found by binary search).  Bit-identical gradients run to run.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
  *                     v_viewmat[16] is overwritten (row 3 = 0). */
@@ -179,7 +186,7 @@ int gsl_fused_project(const float* means, const float* quats, const float* scale
 int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0,
                   int ty1, int tile_n_bits, const int32_t* tile_offsets, int64_t capacity,
                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
-                  size_t ws_bytes, void* stream);
+                  size_t ws_bytes, int write_sorted_keys, void* stream);
 int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
@@ -190,14 +197,16 @@ int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int 
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                         const void* Qh, void* stream);
+                         const void* Qh, float* vrow, void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,
                           float eps2d, int antialiased, int channels, const int32_t* radii,
                           const float* Q1, const float* compensations, float* vacc, float* v_means,
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
-                          float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, void* stream);
+                          float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
+                          const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0, int tile_w,
+                          int tile_h, int ty0, int ty1, int64_t capacity, void* stream);
 
 /* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4
  * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_fused_raster_bwd: instead of

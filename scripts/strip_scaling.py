@@ -3,7 +3,7 @@ rank's strip context in turn on this GPU, replay its graph, and report max-over-
 (excludes the 16-float all-reduce).  python scripts/strip_scaling.py [sigma_px] [order]"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gsplatloc_amd.context import RenderContext
+from gsplatloc_amd.context import RenderContext, time_stages
 from gsplatloc_amd.parallel import strip_rows, gaussians_for_strip
 from gsplatloc_amd.synthetic import random_scene, perturbed_pose
 
@@ -48,6 +48,9 @@ for world in (1, 2, 4, 8):
         for _ in range(20): gr.replay()
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t) / 20 * 1e3)
+        if rank == world // 2:
+            st = time_stages(ctx, inp, v, va, True, steps=10)
+            print(f"   world {world} rank {rank}: rows {rows} n={n} stages " + " ".join(f"{k}={x*1e3:.0f}us" for k, x in st.items()), flush=True)
         del gr, ctx
     worst = max(times)
     base = base or worst

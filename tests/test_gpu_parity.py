@@ -403,6 +403,42 @@ def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
             mostly_close(out["auto"][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
 
 
+@pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB", True)])
+def test_deterministic_backward_is_bit_reproducible(mode, full):
+    """RenderContext(deterministic=True): no float atomics in the backward (per-wave moment rows summed in wave order,
+    one gradient row per intersection, a Gaussian's rows found by binary search and added in tile order), so two runs
+    give bit-identical gradients; and they agree with the default (atomic) backward to rounding."""
+    _gpu()
+    from gsplatloc_amd.context import RenderContext
+    W, H, N = 200, 136, 30000
+    sc = _scene32(N, W, H, sigma_px=1.0, opacity=(0.3, 1.0))
+    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+    ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
+    V = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
+    K = sc["K"].to(DEV).contiguous()
+    gen = torch.Generator().manual_seed(3)
+    D = {"RGB+ED": 4, "ED": 1, "RGB": 3}[mode]
+    v = torch.randn(H, W, D, generator=gen).to(DEV)
+    va = torch.randn(H, W, 1, generator=gen).to(DEV)
+    runs = []
+    for det in (True, True, False):
+        rc = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=DEV, full_grads=full, deterministic=det)
+        rc.calibrate(*ins, V, K)
+        assert not rc.tiny
+        for _ in range(2):
+            rc.forward(*ins, V, K)
+            g = rc.backward(v, va, full=full)
+        rc.check_capacity()
+        runs.append({k: t.clone() for k, t in g.items() if t is not None})
+    for k in runs[0]:
+        assert torch.equal(runs[0][k], runs[1][k]), k          # bit-identical from run to run
+        scale = float(runs[2][k].abs().max())
+        if k == "quats":   # isotropic Gaussians: this gradient is rounding noise of a cancelling sum
+            continue
+        mostly_close(runs[0][k], runs[2][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
+    assert rel_inf(runs[0]["viewmat"], runs[2]["viewmat"]) < 2e-5
+
+
 def test_tiny_backward_reports_a_splat_that_outgrew_its_slab():
     """A context calibrated on pixel-sized splats whose scales then grow (sigma_px = 1: 8+ px wide): the tiny
     backward raises its sticky device flag instead of dropping gradient silently; the caller switches the context
