@@ -200,8 +200,8 @@ def cpu_baseline(args, scene, gpu):
                   "pixels_beyond_tolerance": float(1.0 - ok.mean()),
                   "v_viewmat_rel_err": float(np.abs(gv - wv).max() / np.abs(wv).max()),
                   "v_viewmat_note": "upstream gradient = white noise on the depth channel: a sum of ~1e6 terms of random "
-                                    "sign, i.e. the worst conditioning; with the tracker's loss as the upstream gradient "
-                                    "the error is ~1e-5 (tests/test_gpu_configs.py)",
+                                    "sign (poorly conditioned); tests/test_gpu_configs.py measures this number and the "
+                                    "tracker-loss gradient next to the float32 floor of the oracle's own float32 build",
                   "n_isects": [int(gpu["n_isects"]), int(ref["n_isects"])]}
     return base, parity
 
