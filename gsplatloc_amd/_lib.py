@@ -48,9 +48,12 @@ _SIGNATURES = {
     "gsl_tracking_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_size_t,
                                   P]),
     "gsl_pose_init": (c_int, [P, P, P, c_float, c_float, P, P, P]),
-    "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
-                              c_float, c_float, c_float, c_int, c_int, c_int, c_int, P, P, P, P]),
-    "gsl_pack_pose_reduce": (c_int, [P, P, c_int, P, P]),
+    "gsl_normal_ws_bytes": (c_size_t, [c_int, c_int]),
+    "gsl_normal_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                                P, P, P, c_size_t, P]),
+    "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+                              c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "gsl_pack_pose_reduce": (c_int, [P, P, c_int, P, P, P]),
     "gsl_knn_ws_bytes": (c_size_t, [c_int]),
     "gsl_knn_cells": (c_int, []),
     "gsl_knn_count": (c_int, [P, c_int, P, P, c_size_t, P]),

@@ -249,13 +249,14 @@ class _CtxRender(torch.autograd.Function):
                 g["colors"] if (full and ni[5] and rc.rgb) else None, g["viewmat"] if ni[6] else None, None)
 
 
-def pack_pose_reduce(v_viewmat: Tensor, out16: Tensor, loss_partials: Optional[Tensor] = None) -> None:
+def pack_pose_reduce(v_viewmat: Tensor, out16: Tensor, loss_partials: Optional[Tensor] = None,
+                     normal_sum: Optional[Tensor] = None) -> None:
     """One rank's contribution to the per-iteration all-reduce: out16[0:12] = v_viewmat rows 0..2,
-    out16[12:14] = the sums of loss_partials[n,2] (or 0), written by a kernel of the library -- no torch op, so a
-    captured iteration holds this library's launches only."""
+    out16[12:14] = the sums of loss_partials[n,2] (or 0), out16[14] = normal_sum (or 0), written by a kernel of the
+    library -- no torch op, so a captured iteration holds this library's launches only."""
     n = 0 if loss_partials is None else loss_partials.numel() // 2
-    check(load_library().gsl_pack_pose_reduce(ptr(v_viewmat), ptr(loss_partials), n, ptr(out16), current_stream()),
-          "gsl_pack_pose_reduce")
+    check(load_library().gsl_pack_pose_reduce(ptr(v_viewmat), ptr(loss_partials), n, ptr(normal_sum), ptr(out16),
+                                              current_stream()), "gsl_pack_pose_reduce")
 
 
 def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, full: bool, steps: int = 20) -> Dict:

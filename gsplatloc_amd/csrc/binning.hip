@@ -228,37 +228,32 @@ __global__ __launch_bounds__(256) void k_isect_scatter(const float* __restrict__
 }
 
 // Ascending-only bitonic network on n (arbitrary) 64-bit keys; comparators whose upper index
-// falls past n are skipped (equivalent to +inf padding).  Generic version (any memory), one
-// workgroup barrier per sub-step: used for lists too long for LDS.
-__device__ __forceinline__ void bitonic_sort(uint64_t* a, int n, int tid, int nthreads) {
-  int P = 1;
-  while (P < n) P <<= 1;
-  int half = P >> 1;
-  for (int k = 2; k <= P; k <<= 1) {
-    int hk = k >> 1;
-    for (int i = tid; i < half; i += nthreads) {
-      int blk = i / hk, off = i - blk * hk;
-      int lo = blk * k + off;
-      int hi = blk * k + (k - 1 - off);
-      if (hi < n) {
-        uint64_t x = a[lo], y = a[hi];
-        if (x > y) { a[lo] = y; a[hi] = x; }
-      }
-    }
-    __syncthreads();
-    for (int j = hk >> 1; j >= 1; j >>= 1) {
-      for (int i = tid; i < half; i += nthreads) {
-        int blk = i / j, off = i - blk * j;
-        int lo = blk * 2 * j + off;
-        int hi = lo + j;
-        if (hi < n) {
-          uint64_t x = a[lo], y = a[hi];
-          if (x > y) { a[lo] = y; a[hi] = x; }
-        }
-      }
-      __syncthreads();
+// falls past n are skipped (equivalent to +inf padding).  One comparator sub-step in global memory: used by the
+// long-list sort below for the sub-steps that cross 4096-key blocks.
+__device__ __forceinline__ void bitonic_flip_step(uint64_t* a, int n, int half, int k, int tid, int nthreads) {
+  int hk = k >> 1;
+  for (int i = tid; i < half; i += nthreads) {
+    int blk = i / hk, off = i - blk * hk;
+    int lo = blk * k + off;
+    int hi = blk * k + (k - 1 - off);
+    if (hi < n) {
+      uint64_t x = a[lo], y = a[hi];
+      if (x > y) { a[lo] = y; a[hi] = x; }
     }
   }
+  __syncthreads();
+}
+__device__ __forceinline__ void bitonic_half_step(uint64_t* a, int n, int half, int j, int tid, int nthreads) {
+  for (int i = tid; i < half; i += nthreads) {
+    int blk = i / j, off = i - blk * j;
+    int lo = blk * 2 * j + off;
+    int hi = lo + j;
+    if (hi < n) {
+      uint64_t x = a[lo], y = a[hi];
+      if (x > y) { a[lo] = y; a[hi] = x; }
+    }
+  }
+  __syncthreads();
 }
 
 // LDS version for a 256-thread workgroup.  Each of `nw` working waves owns a contiguous segment
@@ -315,6 +310,40 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
   __syncthreads();
 }
 
+// Lists longer than the LDS capacity (a pile of splats in one tile: e.g. the invalid pixels of a TUM depth frame,
+// which all sit at the previous camera's origin).  Same network, run block-wise: every stage k <= CAP is the LDS sort
+// of one aligned CAP-key block; of a stage k > CAP only the sub-steps at distance >= CAP touch global memory, the
+// remaining log2(CAP) sub-steps stay inside aligned blocks and run in LDS.  For n = 24 k: 6 global sub-steps instead
+// of 120.
+__device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* lds, int tid) {
+  constexpr int CAP = GSL_SORT_LDS_CAP;
+  int nblk = (n + CAP - 1) / CAP;
+  for (int b = 0; b < nblk; ++b) {
+    int nb = min(CAP, n - b * CAP);
+    __syncthreads();
+    for (int i = tid; i < nb; i += 256) lds[i] = a[b * CAP + i];
+    __syncthreads();
+    bitonic_sort_lds(lds, nb, tid);
+    for (int i = tid; i < nb; i += 256) a[b * CAP + i] = lds[i];
+  }
+  __syncthreads();
+  int P = CAP;
+  while (P < n) P <<= 1;
+  int half = P >> 1;
+  for (int k = 2 * CAP; k <= P; k <<= 1) {
+    bitonic_flip_step(a, n, half, k, tid, 256);
+    for (int j = k >> 2; j >= CAP; j >>= 1) bitonic_half_step(a, n, half, j, tid, 256);
+    for (int b = 0; b < nblk; ++b) {
+      int nb = min(CAP, n - b * CAP);
+      for (int i = tid; i < nb; i += 256) lds[i] = a[b * CAP + i];
+      __syncthreads();
+      for (int j = CAP >> 1; j >= 1; j >>= 1) bitonic_half_step(lds, nb, CAP >> 1, j, tid, 256);
+      for (int i = tid; i < nb; i += 256) a[b * CAP + i] = lds[i];
+      __syncthreads();
+    }
+  }
+}
+
 // One workgroup per tile: sort the tile's bucket, write flatten_ids (+ gsplat-style isect_ids).
 __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ tile_offsets, int tile_begin,
                                                    long long capacity, uint64_t* __restrict__ keys,
@@ -340,8 +369,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
       if (write_sorted_keys) src[i] = k;  // (depth bits, id) in list order: the deterministic backward searches them
     }
   } else {
-    __syncthreads();
-    bitonic_sort(src, n, tid, 256);  // rare: huge tile list, sort in place in global memory
+    bitonic_sort_long(src, n, skeys, tid);  // rare: huge tile list, sorted in place block-wise
     for (int i = tid; i < n; i += 256) {
       uint64_t k = src[i];
       flatten_ids[s + i] = (int32_t)(uint32_t)k;

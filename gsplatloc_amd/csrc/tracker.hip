@@ -103,6 +103,163 @@ __global__ __launch_bounds__(256) void k_loss_stage2(const float* __restrict__ r
 }
 
 // ------------------------------------------------------------------------------------------------
+// Normal-consistency term (/root/reference/src/my_gsplat/loss.py:62-101 "cosine", geometry.py:164-197; the call the
+// reference keeps commented out at gs_trainer_total.py:138-143 with normal_lambda = 0, data/base.py:28):
+//   P(i,j)  = depth(i,j) * ((j - cx)/fx, (i - cy)/fy, 1)             back-projection of the masked depth image
+//   n(i,j)  = normalize(dx x dy),  dx/dy = central differences of P with replicated borders, eps 1e-12
+//   loss    = 1 - mean_{i,c} cos_i,c,   cos_i,c = <a_i.c, b_i.c> / (max(|a_i.c|, 1e-8) max(|b_i.c|, 1e-8))
+// where a = normals of the rendered depth, b = normals of the target depth and -- as coded in the reference:
+// F.cosine_similarity(..., dim=1) on [H,W,3] maps -- the similarity runs ALONG EACH IMAGE ROW per component.
+// Four deterministic kernels: row statistics, their sum, the gradient w.r.t. dx/dy per pixel, its gather to depth.
+// ------------------------------------------------------------------------------------------------
+struct Intrin { float fx, fy, cx, cy; };
+
+template <typename F>
+__device__ __forceinline__ void surface_diffs(F img, int i, int j, int H, int W, Intrin k, float dx[3], float dy[3]) {
+  int jl = clampi(j - 1, 0, W - 1), jr = clampi(j + 1, 0, W - 1), iu = clampi(i - 1, 0, H - 1), id = clampi(i + 1, 0, H - 1);
+  float zl = img(i, jl), zr = img(i, jr), zu = img(iu, j), zd = img(id, j);
+  float yi = ((float)i - k.cy) / k.fy, xj = ((float)j - k.cx) / k.fx;
+  dx[0] = ((float)jr - k.cx) / k.fx * zr - ((float)jl - k.cx) / k.fx * zl;
+  dx[1] = yi * zr - yi * zl;
+  dx[2] = zr - zl;
+  dy[0] = xj * zd - xj * zu;
+  dy[1] = ((float)id - k.cy) / k.fy * zd - ((float)iu - k.cy) / k.fy * zu;
+  dy[2] = zd - zu;
+}
+
+__device__ __forceinline__ float unit_normal(const float dx[3], const float dy[3], float n[3]) {
+  float c0 = dx[1] * dy[2] - dx[2] * dy[1], c1 = dx[2] * dy[0] - dx[0] * dy[2], c2 = dx[0] * dy[1] - dx[1] * dy[0];
+  float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  float inv = 1.f / fmaxf(len, 1e-12f);
+  n[0] = c0 * inv; n[1] = c1 * inv; n[2] = c2 * inv;
+  return len;
+}
+
+// One workgroup per owned row: rowstat[i][0..2] = <a,b>, [3..5] = <a,a>, [6..8] = <b,b> per component, [9] = sum_c cos.
+__global__ __launch_bounds__(256) void k_normal_rows(const float* __restrict__ render, int D,
+                                                     const float* __restrict__ gt, int W, int H, int r0, Intrin k,
+                                                     float* __restrict__ rowstat) {
+  int i = r0 + blockIdx.x;
+  auto A = [&](int ii, int jj) { return render[((size_t)ii * W + jj) * D + (D - 1)]; };
+  auto B = [&](int ii, int jj) {
+    float d = render[((size_t)ii * W + jj) * D + (D - 1)];
+    return d != 0.f ? gt[(size_t)ii * W + jj] : 0.f;
+  };
+  float acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) acc[q] = 0.f;
+  for (int j = threadIdx.x; j < W; j += 256) {
+    float dx[3], dy[3], a[3], b[3];
+    surface_diffs(A, i, j, H, W, k, dx, dy);
+    unit_normal(dx, dy, a);
+    surface_diffs(B, i, j, H, W, k, dx, dy);
+    unit_normal(dx, dy, b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { acc[c] += a[c] * b[c]; acc[3 + c] += a[c] * a[c]; acc[6 + c] += b[c] * b[c]; }
+  }
+  __shared__ float red[4][9];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    float s = wave_sum(acc[q]);
+    if (lane == 0) red[wv][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float st[9];
+    for (int q = 0; q < 9; ++q) { st[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q]; rowstat[(size_t)i * 10 + q] = st[q]; }
+    float cs = 0.f;
+    for (int c = 0; c < 3; ++c) cs += st[c] / (fmaxf(sqrtf(st[3 + c]), 1e-8f) * fmaxf(sqrtf(st[6 + c]), 1e-8f));
+    rowstat[(size_t)i * 10 + 9] = cs;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_normal_sum(const float* __restrict__ rowstat, int r0, int r1,
+                                                    float* __restrict__ normal_sum) {
+  float a = 0.f;
+  for (int i = r0 + threadIdx.x; i < r1; i += 256) a += rowstat[(size_t)i * 10 + 9];
+  __shared__ float red[4];
+  float s = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) normal_sum[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// Per owned pixel: d loss / d dx and d loss / d dy of the rendered surface (6 floats).  coef = normal_lambda / (3 H).
+__global__ __launch_bounds__(256) void k_normal_grad(const float* __restrict__ render, int D,
+                                                     const float* __restrict__ gt, int W, int H, int r0, int r1,
+                                                     Intrin k, const float* __restrict__ rowstat, float coef,
+                                                     float* __restrict__ gdxy) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (r1 - r0) * W) return;
+  int i = r0 + idx / W, j = idx - (idx / W) * W;
+  auto A = [&](int ii, int jj) { return render[((size_t)ii * W + jj) * D + (D - 1)]; };
+  auto B = [&](int ii, int jj) {
+    float d = render[((size_t)ii * W + jj) * D + (D - 1)];
+    return d != 0.f ? gt[(size_t)ii * W + jj] : 0.f;
+  };
+  float dx[3], dy[3], a[3], b[3], bx[3], by[3];
+  surface_diffs(B, i, j, H, W, k, bx, by);
+  unit_normal(bx, by, b);
+  surface_diffs(A, i, j, H, W, k, dx, dy);
+  float len = unit_normal(dx, dy, a);
+  const float* st = rowstat + (size_t)i * 10;
+  float ga[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float na = sqrtf(st[3 + c]), nb = sqrtf(st[6 + c]);
+    float da = fmaxf(na, 1e-8f), db = fmaxf(nb, 1e-8f);
+    // torch clamps the norms in place outside autograd: the value uses max(|a|, eps), the norm's own derivative a/|a|
+    float dcos = b[c] / (da * db) - ((na > 0.f) ? st[c] / (da * da * db) * (a[c] / na) : 0.f);
+    ga[c] = -coef * dcos;
+  }
+  float gc[3];
+  if (len > 1e-12f) {
+    float dot = a[0] * ga[0] + a[1] * ga[1] + a[2] * ga[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gc[c] = (ga[c] - a[c] * dot) / len;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gc[c] = ga[c] * 1e12f;
+  }
+  // c = dx x dy  =>  g_dx = dy x g_c,  g_dy = g_c x dx
+  float* o = gdxy + 6 * ((size_t)i * W + j);
+  o[0] = dy[1] * gc[2] - dy[2] * gc[1];
+  o[1] = dy[2] * gc[0] - dy[0] * gc[2];
+  o[2] = dy[0] * gc[1] - dy[1] * gc[0];
+  o[3] = gc[1] * dx[2] - gc[2] * dx[1];
+  o[4] = gc[2] * dx[0] - gc[0] * dx[2];
+  o[5] = gc[0] * dx[1] - gc[1] * dx[0];
+}
+
+// Per pixel of rows [h0,h1): gather the differences that read its point (replicated borders included) and chain to
+// depth through P = depth * ray; ADDED to v_render[...,D-1] (gsl_tracking_loss wrote the other two terms there).
+__global__ __launch_bounds__(256) void k_normal_gather(const float* __restrict__ render, int D, int W, int H, int r0,
+                                                       int r1, int h0, int h1, Intrin k,
+                                                       const float* __restrict__ gdxy, float* __restrict__ v_render) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (h1 - h0) * W) return;
+  int i = h0 + idx / W, j = idx - (idx / W) * W;
+  size_t q = (size_t)i * W + j;
+  if (render[q * D + (D - 1)] == 0.f) return;  // masked pixel: the mask carries no gradient
+  float g[3] = {0.f, 0.f, 0.f};
+  if (i >= r0 && i < r1) {
+    for (int pj = max(j - 1, 0); pj <= min(j + 1, W - 1); ++pj) {
+      const float* o = gdxy + 6 * ((size_t)i * W + pj);
+      float sgn = (clampi(pj + 1, 0, W - 1) == j ? 1.f : 0.f) - (clampi(pj - 1, 0, W - 1) == j ? 1.f : 0.f);
+      g[0] += sgn * o[0]; g[1] += sgn * o[1]; g[2] += sgn * o[2];
+    }
+  }
+  for (int pi = max(i - 1, r0); pi <= min(i + 1, r1 - 1); ++pi) {
+    const float* o = gdxy + 6 * ((size_t)pi * W + j) + 3;
+    float sgn = (clampi(pi + 1, 0, H - 1) == i ? 1.f : 0.f) - (clampi(pi - 1, 0, H - 1) == i ? 1.f : 0.f);
+    g[0] += sgn * o[0]; g[1] += sgn * o[1]; g[2] += sgn * o[2];
+  }
+  float xr = ((float)j - k.cx) / k.fx, yr = ((float)i - k.cy) / k.fy;
+  v_render[q * D + (D - 1)] += g[0] * xr + g[1] * yr + g[2];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pose state (device resident, one per tracker):
 //   f[0..3] quat (wxyz)  f[4..6] t      f[7..13] Adam exp_avg   f[14..20] Adam exp_avg_sq
 //   f[21] lr_quat f[22] lr_trans        f[23] best_loss f[24] best_depth f[25] best_edge
@@ -110,7 +267,7 @@ __global__ __launch_bounds__(256) void k_loss_stage2(const float* __restrict__ r
 //   i[0] step  i[1] counter  i[2] stopped  i[3] best_step
 // ------------------------------------------------------------------------------------------------
 struct PoseHyper {
-  float beta1, beta2, eps, wd_quat, wd_trans, gamma, depth_w, edge_w, inv_P;
+  float beta1, beta2, eps, wd_quat, wd_trans, gamma, depth_w, edge_w, inv_P, normal_w, inv_3H;
   int min_step, patience, early_stop, max_steps;
 };
 
@@ -177,6 +334,7 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
                                                    const float* __restrict__ v_viewmat,
                                                    const float* __restrict__ partial, int nb,
                                                    const float* __restrict__ loss_sums_in,
+                                                   const float* __restrict__ normal_sum,
                                                    const float* __restrict__ gt_c2w, PoseHyper hp,
                                                    float* __restrict__ c2w, float* __restrict__ viewmat,
                                                    float* __restrict__ loss_hist) {
@@ -200,6 +358,10 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   int step = istate[0];
   float depth_loss = sums[0] * hp.inv_P, edge_loss = sums[1] * hp.inv_P;
   float total = hp.depth_w * depth_loss + hp.edge_w * edge_loss;
+  if (hp.normal_w != 0.f) {  // sum of the row cosines: this rank's (normal_sum) or all ranks' (loss_sums_in[2])
+    float cs = loss_sums_in ? loss_sums_in[2] : (normal_sum ? normal_sum[0] : 0.f);
+    total += hp.normal_w * (1.f - cs * hp.inv_3H);
+  }
   float q[4] = {f[0], f[1], f[2], f[3]}, t[3] = {f[4], f[5], f[6]};
   float R[9], qh[4], qn;
   quat_to_R(q, R, qh, qn);
@@ -289,9 +451,11 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
 }
 
 // The 16 floats one rank contributes to the per-iteration all-reduce: 12 pose-gradient entries (rows 0..2 of
-// d loss / d viewmat) and its two loss sums (fixed-order sum of its block partials); entries 14, 15 are zero.
+// d loss / d viewmat), its two loss sums (fixed-order sum of its block partials) and, in entry 14, its sum of row
+// cosines of the normal-consistency term (0 when that term is off); entry 15 is zero.
 __global__ __launch_bounds__(256) void k_pack_pose_reduce(const float* __restrict__ v_viewmat,
                                                           const float* __restrict__ partial, int nb,
+                                                          const float* __restrict__ normal_sum,
                                                           float* __restrict__ out16) {
   __shared__ float red[4][2];
   float a0 = 0.f, a1 = 0.f;
@@ -303,16 +467,17 @@ __global__ __launch_bounds__(256) void k_pack_pose_reduce(const float* __restric
   if (threadIdx.x < 12) out16[threadIdx.x] = v_viewmat[threadIdx.x];
   else if (threadIdx.x < 14)
     out16[threadIdx.x] = red[0][threadIdx.x - 12] + red[1][threadIdx.x - 12] + red[2][threadIdx.x - 12] + red[3][threadIdx.x - 12];
-  else if (threadIdx.x < 16) out16[threadIdx.x] = 0.f;
+  else if (threadIdx.x == 14) out16[14] = normal_sum ? normal_sum[0] : 0.f;
+  else if (threadIdx.x == 15) out16[15] = 0.f;
 }
 
 }  // namespace gsl
 
-extern "C" int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials, float* out16,
-                                    void* stream) {
+extern "C" int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials,
+                                    const float* normal_sum, float* out16, void* stream) {
   if (!v_viewmat || !out16 || n_partials < 0 || (n_partials > 0 && !loss_partials)) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_pack_pose_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, v_viewmat, loss_partials,
-                     n_partials, out16);
+                     n_partials, normal_sum, out16);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -349,6 +514,44 @@ extern "C" int gsl_tracking_loss(const float* render, int channels, const float*
   return GSL_OK;
 }
 
+extern "C" size_t gsl_normal_ws_bytes(int width, int height) {
+  size_t P = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
+  return (P * 6 + (size_t)(height > 0 ? height : 0) * 10) * sizeof(float);
+}
+
+extern "C" int gsl_normal_loss(const float* render, int channels, const float* depth_gt, int width, int height,
+                               int row0, int row1, float fx, float fy, float cx, float cy, float normal_lambda,
+                               float* v_render, float* normal_sum, void* ws, size_t ws_bytes, void* stream) {
+  if (width <= 0 || height <= 0 || channels <= 0 || row0 < 0 || row1 > height || row0 > row1) return GSL_ERR_BAD_ARG;
+  if (!render || !depth_gt || !v_render || !normal_sum || !ws || fx == 0.f || fy == 0.f) return GSL_ERR_BAD_ARG;
+  if (ws_bytes < gsl_normal_ws_bytes(width, height)) return GSL_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  size_t P = (size_t)width * height;
+  float* gdxy = (float*)ws;
+  float* rowstat = gdxy + 6 * P;
+  gsl::Intrin k{fx, fy, cx, cy};
+  if (row1 == row0) {  // empty strip: contributes 0
+    hipLaunchKernelGGL(gsl::k_normal_sum, dim3(1), dim3(256), 0, st, rowstat, 0, 0, normal_sum);
+    GSL_CHECK_LAUNCH();
+    return GSL_OK;
+  }
+  hipLaunchKernelGGL(gsl::k_normal_rows, dim3(row1 - row0), dim3(256), 0, st, render, channels, depth_gt, width, height,
+                     row0, k, rowstat);
+  GSL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gsl::k_normal_sum, dim3(1), dim3(256), 0, st, rowstat, row0, row1, normal_sum);
+  GSL_CHECK_LAUNCH();
+  int nown = (row1 - row0) * width;
+  hipLaunchKernelGGL(gsl::k_normal_grad, dim3((nown + 255) / 256), dim3(256), 0, st, render, channels, depth_gt, width,
+                     height, row0, row1, k, rowstat, normal_lambda / (3.0f * (float)height), gdxy);
+  GSL_CHECK_LAUNCH();
+  int h0 = row0 > 0 ? row0 - 1 : 0, h1 = row1 < height ? row1 + 1 : height;
+  int n2 = (h1 - h0) * width;
+  hipLaunchKernelGGL(gsl::k_normal_gather, dim3((n2 + 255) / 256), dim3(256), 0, st, render, channels, width, height,
+                     row0, row1, h0, h1, k, gdxy, v_render);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
 extern "C" int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, float lr_quat, float lr_trans,
                              float* c2w, float* viewmat, void* stream) {
   if (!pose_f || !pose_i || !init_c2w || !c2w || !viewmat) return GSL_ERR_BAD_ARG;
@@ -359,8 +562,9 @@ extern "C" int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, 
 }
 
 extern "C" int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* loss_partials,
-                             int n_partials, const float* loss_sums, const float* gt_c2w, int width, int height,
-                             float depth_lambda, float edge_lambda, float beta1, float beta2, float eps,
+                             int n_partials, const float* loss_sums, const float* normal_sum, const float* gt_c2w,
+                             int width, int height, float depth_lambda, float edge_lambda, float normal_lambda,
+                             float beta1, float beta2, float eps,
                              float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
                              int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream) {
   if (!pose_f || !pose_i || !v_viewmat || !gt_c2w || !c2w || !viewmat) return GSL_ERR_BAD_ARG;
@@ -369,9 +573,10 @@ extern "C" int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat,
   gsl::PoseHyper hp;
   hp.beta1 = beta1; hp.beta2 = beta2; hp.eps = eps; hp.wd_quat = wd_quat; hp.wd_trans = wd_trans; hp.gamma = gamma;
   hp.depth_w = depth_lambda; hp.edge_w = edge_lambda; hp.inv_P = 1.0f / ((float)width * (float)height);
+  hp.normal_w = normal_lambda; hp.inv_3H = 1.0f / (3.0f * (float)height);
   hp.min_step = min_step; hp.patience = patience; hp.early_stop = early_stop; hp.max_steps = max_steps;
   hipLaunchKernelGGL(gsl::k_pose_step, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_f, pose_i, v_viewmat,
-                     loss_partials, n_partials, loss_sums, gt_c2w, hp, c2w, viewmat, loss_hist);
+                     loss_partials, n_partials, loss_sums, normal_sum, gt_c2w, hp, c2w, viewmat, loss_hist);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -79,8 +79,14 @@ class GraphTracker:
         self.n_partials = ((self.row1 - self.row0) * self.W + 255) // 256
         self.partials = torch.zeros(max(self.n_partials, 1) * 2, dtype=f32, device=d)
         self.loss_hist = torch.zeros(max(config.max_steps, 1), dtype=f32, device=d)
-        self.reduce_buf = torch.zeros(16, dtype=f32, device=d)  # 12 pose-gradient entries + 2 loss sums
+        self.reduce_buf = torch.zeros(16, dtype=f32, device=d)  # 12 pose-gradient entries + 2 loss sums + row cosines
+        self.normal_sum = self.normal_ws = None
+        if config.normal_lambda != 0.0:  # the term the reference keeps switched off (gs_trainer_total.py:138-143)
+            self.normal_ws_bytes = self.lib.gsl_normal_ws_bytes(self.W, self.H)
+            self.normal_ws = torch.zeros(self.normal_ws_bytes, dtype=torch.uint8, device=d)
+            self.normal_sum = torch.zeros(1, dtype=f32, device=d)
         self._host16 = None
+        self._intrinsics = (1.0, 1.0, 0.0, 0.0)
         self.graph = self.graph_tail = None
         self._side = torch.cuda.Stream(device=d)
         self.headroom = 1.5
@@ -98,6 +104,8 @@ class GraphTracker:
         self.sh[:, 0, :] = rgb_to_sh(colors.to(self.dev))
         self.opac.copy_(torch.sigmoid(torch.logit(torch.full((self.N,), self.cfg.gs.init_opa, device=self.dev))))
         self.K.copy_(K)
+        Kh = K.detach().cpu()
+        self._intrinsics = (float(Kh[0, 0]), float(Kh[1, 1]), float(Kh[0, 2]), float(Kh[1, 2]))
         self.gt_depth.copy_(src_depth.reshape(self.H, self.W))
         self.init_c2w.copy_(tar_c2w)
         self.gt_c2w.copy_(src_c2w)
@@ -121,10 +129,15 @@ class GraphTracker:
         check(lib.gsl_tracking_loss(ptr(self.rc.render), self.rc.D, ptr(self.gt_depth), self.W, self.H, self.row0,
                                     self.row1, cfg.depth_lambda, edge_w, ptr(self.v_render), ptr(self.partials), None,
                                     ptr(self.loss_ws), self.loss_ws_bytes, st), "gsl_tracking_loss")
+        if self.normal_ws is not None:
+            check(lib.gsl_normal_loss(ptr(self.rc.render), self.rc.D, ptr(self.gt_depth), self.W, self.H, self.row0,
+                                      self.row1, *self._intrinsics, cfg.normal_lambda, ptr(self.v_render),
+                                      ptr(self.normal_sum), ptr(self.normal_ws), self.normal_ws_bytes, st),
+                  "gsl_normal_loss")
         self.rc.backward(self.v_render, self.v_alphas, full=False)
         if self.group is not None:
             check(lib.gsl_pack_pose_reduce(ptr(self.rc.v_viewmat), ptr(self.partials), self.n_partials,
-                                           ptr(self.reduce_buf), st), "gsl_pack_pose_reduce")
+                                           ptr(self.normal_sum), ptr(self.reduce_buf), st), "gsl_pack_pose_reduce")
 
     def _pose_step(self) -> None:
         cfg, lib = self.cfg, self.lib
@@ -136,8 +149,9 @@ class GraphTracker:
         edge_w = 1.0 - cfg.depth_lambda - cfg.normal_lambda
         gamma = 0.2 ** (1.0 / cfg.max_steps)
         check(lib.gsl_pose_step(ptr(self.pose_f), ptr(self.pose_i), v_viewmat, ptr(self.partials),
-                                self.n_partials, loss_sums, ptr(self.gt_c2w), self.W, self.H, cfg.depth_lambda,
-                                edge_w, 0.9, 0.999, 1e-8, cam.quat_opt_reg, cam.trans_opt_reg, gamma, cfg.min_step,
+                                self.n_partials, loss_sums, ptr(self.normal_sum), ptr(self.gt_c2w), self.W, self.H,
+                                cfg.depth_lambda, edge_w, cfg.normal_lambda, 0.9, 0.999, 1e-8, cam.quat_opt_reg,
+                                cam.trans_opt_reg, gamma, cfg.min_step,
                                 cfg.patience, int(cfg.early_stop), cfg.max_steps, ptr(self.c2w), ptr(self.viewmat),
                                 ptr(self.loss_hist), current_stream()), "gsl_pose_step")
 

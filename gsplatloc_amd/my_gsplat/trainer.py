@@ -20,7 +20,7 @@ import torch
 from torch import Tensor
 
 from ..context import RenderContext
-from .loss import compute_depth_loss, compute_silhouette_loss
+from .loss import compute_depth_loss, compute_normal_consistency_loss, compute_silhouette_loss
 from .model import CameraConfig, CameraOptModule_quat_tans, GsConfig, GSModel
 
 
@@ -70,13 +70,19 @@ class PoseTracker:
         self.config = config
         self.engine = engine
 
-    def tracking_loss(self, depths: Tensor, depths_gt: Tensor):
-        """gs_trainer_total.py:105-150."""
+    def tracking_loss(self, depths: Tensor, depths_gt: Tensor, K: Optional[Tensor] = None):
+        """gs_trainer_total.py:105-150.  The normal-consistency term is the call the reference keeps commented
+        out (:138-143) behind normal_lambda = 0 (data/base.py:28); it is evaluated only for a non-zero weight."""
         mask = (depths != 0).float()
         depth_loss = compute_depth_loss(depths * mask, depths_gt * mask, loss_type="l1")
         silhouette_loss = compute_silhouette_loss(depths * mask, depths_gt * mask, loss_type="l1")
         total = depth_loss * self.config.depth_lambda + silhouette_loss * (
             1 - self.config.depth_lambda - self.config.normal_lambda)
+        if self.config.normal_lambda != 0.0:
+            assert K is not None, "the normal-consistency term back-projects through K"
+            normal_loss = compute_normal_consistency_loss((depths * mask)[0, :, :, 0], (depths_gt * mask)[0, :, :, 0],
+                                                          K=K, loss_type="cosine")
+            total = total + normal_loss * self.config.normal_lambda
         return total, depth_loss, silhouette_loss
 
     def track_frame(self, tar_points: Tensor, colors: Tensor, src_depth: Tensor, tar_c2w: Tensor, src_c2w: Tensor,
@@ -115,7 +121,7 @@ class PoseTracker:
                 renders = render.unsqueeze(0)
             assert renders.shape[-1] == 4
             depths = renders[..., 3:4]
-            total_loss, depth_loss, silhouette_loss = self.tracking_loss(depths, src_depth)
+            total_loss, depth_loss, silhouette_loss = self.tracking_loss(depths, src_depth, K)
             total_loss.backward()
             with torch.no_grad():
                 lv = total_loss.item()

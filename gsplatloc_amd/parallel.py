@@ -14,7 +14,7 @@ The pose moves by far less than a tile during a frame's optimisation; ``guard_ti
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Optional, List, Sequence, Tuple
 
 import torch
 from torch import Tensor
@@ -76,7 +76,8 @@ def halo_pixel_rows(rows: Tuple[int, int], height: int, tile_size: int = 16) -> 
 
 
 def strip_tracking_loss(depths: Tensor, depths_gt: Tensor, rows: Tuple[int, int], height: int,
-                        depth_lambda: float = 0.8, normal_lambda: float = 0.0, tile_size: int = 16):
+                        depth_lambda: float = 0.8, normal_lambda: float = 0.0, tile_size: int = 16,
+                        K: Optional[Tensor] = None):
     """This rank's share of the tracker's loss (/root/reference/src/my_gsplat/gs_trainer_total.py:105-150):
     the L1 depth and L1 Sobel-edge terms of the pixel rows it owns, normalised by the FULL image size, so
     that the shares of all ranks add up to the single-GPU loss and their pose gradients to its gradient.
@@ -100,4 +101,16 @@ def strip_tracking_loss(depths: Tensor, depths_gt: Tensor, rows: Tuple[int, int]
     eb = sobel(gm.permute(0, 3, 1, 2))
     sil_share = (ea[:, :, own] - eb[:, :, own]).abs().sum() / P
     total = depth_share * depth_lambda + sil_share * (1 - depth_lambda - normal_lambda)
+    if normal_lambda != 0.0:
+        # the (switched-off) normal term of the reference is a mean over image rows of row-wise cosines
+        # (loss.py:62-101 with dim=1 on [H,W,3] maps): a rank owns the cosines of its rows
+        import torch.nn.functional as F
+        from .my_gsplat.geometry import depth_to_normal
+        keep = torch.zeros_like(depths)
+        keep[:, h0:h1] = 1.0
+        m_all = (depths != 0).float() * keep
+        na = depth_to_normal((depths * m_all)[0, :, :, 0], K)
+        nb = depth_to_normal((depths_gt * m_all)[0, :, :, 0], K)
+        cos = F.cosine_similarity(na[r0:r1], nb[r0:r1], dim=1)  # [rows, 3]
+        total = total + normal_lambda * ((r1 - r0) / float(height) - cos.sum() / (3.0 * height))
     return total, depth_share, sil_share

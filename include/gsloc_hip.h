@@ -238,24 +238,38 @@ int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int 
  * gsl_pose_step : finish the loss, pose errors vs gt_c2w, early-stop bookkeeping (best loss after min_step,
  *   patience), pose chain viewmat->(quat,t), two Adam updates (weight decay in the gradient), lr *= gamma,
  *   new c2w / viewmat; appends the loss to loss_hist[max_steps] (may be NULL).  Does nothing once stopped
- *   (pose_i[2]).  loss_sums[2] (already summed over ranks) overrides loss_partials when not NULL. */
+ *   (pose_i[2]).  loss_sums[3] (already summed over ranks: the two sums and the row-cosine sum) overrides
+ *   loss_partials / normal_sum when not NULL.  normal_lambda != 0 adds normal_lambda * (1 - normal_sum / (3 height)).
+ * gsl_normal_loss: the normal-consistency term the reference defines and keeps switched off (loss.py:62-101 "cosine",
+ *   geometry.py:164-197; call commented out at gs_trainer_total.py:138-143, normal_lambda = 0 at data/base.py:28):
+ *   unit normals of the back-projected masked depth images (central differences, replicated borders), cosine
+ *   similarity ALONG EACH IMAGE ROW per component as the reference codes it, loss = 1 - mean.  Adds
+ *   normal_lambda * d loss / d depth to v_render[...,channels-1] for rows [row0-1,row1+1) (call it after
+ *   gsl_tracking_loss, which writes that channel) and writes the sum of the owned rows' cosines to normal_sum[0].
+ *   ws: gsl_normal_ws_bytes. */
 size_t gsl_loss_ws_bytes(int width, int height);
+size_t gsl_normal_ws_bytes(int width, int height);
+int gsl_normal_loss(const float* render, int channels, const float* depth_gt, int width, int height, int row0,
+                    int row1, float fx, float fy, float cx, float cy, float normal_lambda, float* v_render,
+                    float* normal_sum, void* ws, size_t ws_bytes, void* stream);
 int gsl_tracking_loss(const float* render, int channels, const float* depth_gt, int width, int height,
                       int row0, int row1, float depth_lambda, float edge_lambda, float* v_render,
                       float* loss_partials, int* n_partials_host, void* ws, size_t ws_bytes, void* stream);
 int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, float lr_quat, float lr_trans,
                   float* c2w, float* viewmat, void* stream);
 int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* loss_partials,
-                  int n_partials, const float* loss_sums, const float* gt_c2w, int width, int height,
-                  float depth_lambda, float edge_lambda, float beta1, float beta2, float eps,
+                  int n_partials, const float* loss_sums, const float* normal_sum, const float* gt_c2w,
+                  int width, int height, float depth_lambda, float edge_lambda, float normal_lambda,
+                  float beta1, float beta2, float eps,
                   float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
                   int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream);
 /* Several GPUs: what one rank contributes to the ONE all-reduce of an iteration.  out16[0..11] =
  * v_viewmat[0..11] of its strip, out16[12..13] = its (sum |d - g|, sum |S(d) - S(g)|) over loss_partials[n][2]
- * (fixed order), out16[14..15] = 0.  After the all-reduce (sum) gsl_pose_step takes v_viewmat = out16 and
- * loss_sums = out16 + 12.  Written by a kernel of this library so that a captured iteration holds no foreign node. */
-int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials, float* out16,
-                         void* stream);
+ * (fixed order), out16[14] = normal_sum[0] (0 when NULL), out16[15] = 0.  After the all-reduce (sum) gsl_pose_step
+ * takes v_viewmat = out16 and loss_sums = out16 + 12.  Written by a kernel of this library so that a captured
+ * iteration holds no foreign node. */
+int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials,
+                         const float* normal_sum, float* out16, void* stream);
 
 /* ---- per-frame set-up: exact k nearest neighbours on the device (csrc/knn.hip) ----
  * Stands in for the small_gicp KdTree search of /root/reference/src/my_gsplat/utils.py:16-22.

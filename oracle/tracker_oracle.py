@@ -118,12 +118,36 @@ def compute_silhouette_loss(a: Tensor, b: Tensor) -> Tensor:
     return F.l1_loss(sobel(a.permute(0, 3, 1, 2)), sobel(b.permute(0, 3, 1, 2)))
 
 
-def tracking_loss(depths: Tensor, depths_gt: Tensor, depth_lambda: float = 0.8, normal_lambda: float = 0.0):
-    """gs_trainer_total.py:105-150.  depths, depths_gt: [1,H,W,1]."""
+def depth_to_normal(depth: Tensor, K: Tensor) -> Tensor:
+    """geometry.py:164-197 with depth_to_points :138-161 (kornia.geometry.depth_to_3d_v2: pixel (u, v) on the integer
+    grid -> depth * K^-1 (u, v, 1)): central differences of the back-projected surface with replicated borders,
+    cross product, F.normalize.  depth [H,W] -> [H,W,3]."""
+    H, W = depth.shape
+    v, u = torch.meshgrid(torch.arange(H, dtype=depth.dtype), torch.arange(W, dtype=depth.dtype), indexing="ij")
+    pts = torch.stack([(u - K[0, 2]) / K[0, 0] * depth, (v - K[1, 2]) / K[1, 1] * depth, depth], -1)[None]
+    pp = F.pad(pts, (0, 0, 1, 1, 1, 1), mode="replicate")
+    dx = pp[:, 1:-1, 2:, :] - pp[:, 1:-1, :-2, :]
+    dy = pp[:, 2:, 1:-1, :] - pp[:, :-2, 1:-1, :]
+    return F.normalize(torch.cross(dx, dy, dim=-1), p=2, dim=-1)[0]
+
+
+def compute_normal_consistency_loss(depth_real: Tensor, depth_rendered: Tensor, K: Tensor) -> Tensor:
+    """loss.py:62-101, loss_type "cosine", as coded: the maps are [H,W,3] and the similarity is taken over dim=1, i.e.
+    along each image row per component."""
+    return 1 - F.cosine_similarity(depth_to_normal(depth_real, K), depth_to_normal(depth_rendered, K), dim=1).mean()
+
+
+def tracking_loss(depths: Tensor, depths_gt: Tensor, depth_lambda: float = 0.8, normal_lambda: float = 0.0,
+                  K: Tensor = None):
+    """gs_trainer_total.py:105-150.  depths, depths_gt: [1,H,W,1].  The normal term is the call the reference keeps
+    commented out (:138-143; normal_lambda = 0 in data/base.py:28); evaluated only for a non-zero weight."""
     mask = (depths != 0).to(depths.dtype).detach()
     dl = compute_depth_loss(depths * mask, depths_gt * mask)
     sl = compute_silhouette_loss(depths * mask, depths_gt * mask)
     total = dl * depth_lambda + sl * (1 - depth_lambda - normal_lambda)
+    if normal_lambda != 0.0:
+        nl = compute_normal_consistency_loss((depths * mask)[0, :, :, 0], (depths_gt * mask)[0, :, :, 0], K.to(depths.dtype))
+        total = total + nl * normal_lambda
     return total, dl, sl
 
 

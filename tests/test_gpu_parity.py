@@ -141,10 +141,11 @@ def test_binning_multi_camera_and_empty():
     assert off.shape == (2, th, tw) and int(off.abs().sum()) == 0
 
 
-def test_binning_long_tile_list_uses_global_sort():
-    """> 8192 intersections in one tile exercises the global-memory sort path."""
+@pytest.mark.parametrize("N", [4097, 8192, 12289, 20000, 70001])
+def test_binning_long_tile_list_uses_global_sort(N):
+    """More intersections in one tile than the LDS sort holds (4096): the block-wise long-list sort, with whole and
+    partial last blocks and 1 to 5 cross-block stages."""
     A = _gpu()
-    N = 20000
     g = torch.Generator().manual_seed(3)
     m2 = (torch.rand(1, N, 2, generator=g) * 14 + 1).float()
     r = torch.full((1, N), 1, dtype=torch.int32)

@@ -120,6 +120,86 @@ def test_fused_loss_kernel_matches_autograd_loss():
         assert float(v[..., :3].abs().max()) == 0.0
 
 
+def test_fused_normal_loss_kernel_matches_autograd_loss():
+    """gsl_normal_loss (the normal-consistency term the reference keeps switched off: row-wise cosine of the normal
+    maps of the masked depth images) on top of gsl_tracking_loss vs autograd of the float64 oracle loss, whole image
+    and a strip with its one-row halo.  Tolerance: 2e-4 of the largest gradient entry (float32 cross products of
+    central differences against float64)."""
+    import oracle.tracker_oracle as TO
+    from gsplatloc_amd._lib import check, load_library, ptr
+    from gsplatloc_amd.parallel import strip_tracking_loss
+    from gsplatloc_amd.synthetic import replica_intrinsics
+    lib = load_library()
+    W, H, D = 75, 52, 4
+    K = replica_intrinsics(W, H, dtype=torch.float64)
+    g = torch.Generator().manual_seed(5)
+    gt = torch.rand(H, W, generator=g, dtype=torch.float64) * 3 + 0.5
+    render = torch.rand(H, W, D, generator=g, dtype=torch.float64)
+    render[..., 3] = gt + 0.05 * torch.randn(H, W, generator=g, dtype=torch.float64)
+    render[5:9, 10:30, 3] = 0.0           # holes: mask = (depth != 0)
+    render[:, 0, 3] = 0.0
+    render, gt = render.float().double(), gt.float().double()  # the values the kernels see
+    r32, gt32 = render.float().to(DEV), gt.float().to(DEV)
+    ws_bytes, nws_bytes = lib.gsl_loss_ws_bytes(W, H), lib.gsl_normal_ws_bytes(W, H)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=DEV)
+    nws = torch.zeros(nws_bytes, dtype=torch.uint8, device=DEV)
+    lam_d, lam_n = 0.7, 0.1
+    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+    for rows in (None, (1, 3), (0, 1)):
+        r = render.clone().requires_grad_()
+        depths = r[None, ..., 3:4]
+        if rows is None:
+            total, dl, sl = TO.tracking_loss(depths, gt[None, ..., None], lam_d, lam_n, K)
+            row0, row1 = 0, H
+        else:
+            total, dl, sl = strip_tracking_loss(depths, gt[None, ..., None], rows, H, lam_d, lam_n, K=K)
+            row0, row1 = rows[0] * 16, min(rows[1] * 16, H)
+        total.backward()
+        v = torch.zeros(H, W, D, device=DEV)
+        nb = ((row1 - row0) * W + 255) // 256
+        partials = torch.zeros(nb * 2, device=DEV)
+        nsum = torch.full((1,), -7.0, device=DEV)
+        check(lib.gsl_tracking_loss(ptr(r32), D, ptr(gt32), W, H, row0, row1, lam_d, 1 - lam_d - lam_n, ptr(v),
+                                    ptr(partials), None, ptr(ws), ws_bytes, None), "loss")
+        check(lib.gsl_normal_loss(ptr(r32), D, ptr(gt32), W, H, row0, row1, fx, fy, cx, cy, lam_n, ptr(v), ptr(nsum),
+                                  ptr(nws), nws_bytes, None), "normal")
+        torch.cuda.synchronize()
+        sums = partials.view(-1, 2).sum(0).double().cpu() / (W * H)
+        value = lam_d * sums[0] + (1 - lam_d - lam_n) * sums[1] + lam_n * ((row1 - row0) / H - float(nsum) / (3 * H))
+        assert abs(float(value) - float(total)) < 2e-5 * abs(float(total)), (float(value), float(total))
+        ref = r.grad[..., 3]
+        err = float((v[..., 3].double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        print(f"[parity] normal-consistency term rows={rows}: value rel {abs(float(value) - float(total)) / abs(float(total)):.1e}, "
+              f"v_depth rel-inf {err:.1e}")
+        assert err < 2e-4, err
+        assert float(v[..., :3].abs().max()) == 0.0
+
+
+def test_graph_tracker_with_the_normal_term_follows_the_autograd_tracker():
+    """normal_lambda != 0 end to end: the device loop (loss kernels + normal kernels + pose step in one graph) against
+    the PyTorch loop with the same weights."""
+    M, fp, K, pts0, pts1, scales0, scales1 = _setup()
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    W, H = fp["W"], fp["H"]
+    src_depth = M.compute_depth_gt(pts1.to(DEV), fp["rgb"].to(DEV), K[None].to(DEV), torch.eye(4, device=DEV)[None], H, W)
+    src_depth = src_depth[None, ..., None]
+    steps = 30
+    cfg = M.TrackerConfig(max_steps=steps, min_step=5, patience=1000, depth_lambda=0.7, normal_lambda=0.05)
+    ref = M.PoseTracker(cfg, engine="context").track_frame(
+        pts0.to(DEV), fp["rgb"].to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV), K.to(DEV), W, H,
+        scales=scales0.to(DEV))
+    gt = GraphTracker(pts0.shape[0], W, H, cfg)
+    gt.load_frame(pts0.to(DEV), fp["rgb"].to(DEV), scales0.to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV),
+                  K.to(DEV))
+    res = gt.run()
+    assert res.steps == ref.steps == steps
+    lg, lr = torch.tensor(res.losses), torch.tensor(ref.losses)
+    rel = float(((lg - lr).abs() / lr).max())
+    print(f"[parity] tracker with normal term: loss0 rel {abs(float(lg[0] - lr[0])) / float(lr[0]):.1e}, trajectory rel {rel:.1e}")
+    assert abs(float(lg[0] - lr[0])) < 2e-5 * float(lr[0])
+    assert rel < 5e-3, rel  # Adam amplifies float32 differences of the first updates (same bound as the two-engine test)
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_graph_tracker_matches_pose_tracker(use_graph):
     """Device-side loss + pose chain + Adam + LR decay + early-stop bookkeeping reproduce the PyTorch loop."""

@@ -66,9 +66,20 @@ def test_tracker_kernel_calls_marshal():
                                                             ptr(partials), None, ptr(ws), ws_bytes, None), "loss"), "loss")
     _expect_hip_refusal(lambda: check(lib.gsl_pose_init(ptr(pose_f), ptr(pose_i), ptr(eye), 5e-4, 1e-3, ptr(c2w),
                                                         ptr(viewmat), None), "pose_init"), "pose init")
+    nws_bytes = lib.gsl_normal_ws_bytes(W, H)
+    assert nws_bytes == (W * H * 6 + H * 10) * 4
+    nws, nsum = torch.zeros(nws_bytes, dtype=torch.uint8), torch.zeros(1)
+    _expect_hip_refusal(lambda: check(lib.gsl_normal_loss(ptr(render), D, ptr(gt), W, H, 0, H, 300.0, 300.0, 31.5, 23.5, 0.1,
+                                                          ptr(v_render), ptr(nsum), ptr(nws), nws_bytes, None), "normal"),
+                        "normal loss")
+    assert lib.gsl_normal_loss(ptr(render), D, ptr(gt), W, H, 0, H, 0.0, 300.0, 31.5, 23.5, 0.1, ptr(v_render), ptr(nsum),
+                               ptr(nws), nws_bytes, None) == -1  # fx = 0: bad argument, checked before any launch
+    assert lib.gsl_normal_loss(ptr(render), D, ptr(gt), W, H, 0, H, 300.0, 300.0, 31.5, 23.5, 0.1, ptr(v_render), ptr(nsum),
+                               ptr(nws), nws_bytes - 4, None) < 0  # workspace too small
     _expect_hip_refusal(lambda: check(lib.gsl_pose_step(ptr(pose_f), ptr(pose_i), ptr(v_viewmat), ptr(partials), n_part,
-                                                        None, ptr(eye), W, H, 0.8, 0.2, 0.9, 0.999, 1e-8, 1e-3, 1e-3,
-                                                        0.99, 100, 200, 1, 10, ptr(c2w), ptr(viewmat), ptr(hist), None),
+                                                        None, ptr(nsum), ptr(eye), W, H, 0.7, 0.2, 0.1, 0.9, 0.999, 1e-8,
+                                                        1e-3, 1e-3, 0.99, 100, 200, 1, 10, ptr(c2w), ptr(viewmat),
+                                                        ptr(hist), None),
                                       "pose_step"), "pose step")
     # k-NN set-up
     pts, bbox = torch.rand(100, 3), torch.tensor([0.0, 0, 0, 1, 1, 1])

@@ -157,6 +157,43 @@ def test_loss_mirror_matches_the_oracle_restatement():
         L.compute_silhouette_loss(a, b, loss_type="huber")
 
 
+def test_normal_consistency_term_mirror_oracle_and_tracker_weighting():
+    """The term the reference defines and keeps switched off (loss.py:62-101, gs_trainer_total.py:138-143): the host
+    mirror, the oracle restatement and the weighting inside tracking_loss agree; as coded, the cosine runs along
+    each image row per component (dim=1 of [H,W,3])."""
+    import torch.nn.functional as F
+    from gsplatloc_amd.my_gsplat import loss as L
+    from gsplatloc_amd.my_gsplat.trainer import PoseTracker, TrackerConfig
+    from gsplatloc_amd.synthetic import replica_intrinsics
+
+    g = torch.Generator().manual_seed(8)
+    H, W = 23, 31
+    K = replica_intrinsics(W, H, dtype=torch.float64)
+    a = torch.rand(H, W, generator=g, dtype=torch.float64) * 2 + 1
+    b = a + 0.05 * torch.randn(H, W, generator=g, dtype=torch.float64)
+    a[4:7, 9:15] = 0.0
+    na, no = L.depth_to_normal(a, K), TO.depth_to_normal(a, K)
+    torch.testing.assert_close(na, no, rtol=1e-12, atol=1e-14)
+    assert torch.allclose(na.norm(dim=-1)[a > 0][:50], torch.ones(50, dtype=torch.float64))
+    # a fronto-parallel plane: dx x dy with x to the right and y down points along +z, as coded
+    flat = TO.depth_to_normal(torch.full((5, 6), 2.0, dtype=torch.float64), K)
+    assert torch.allclose(flat, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).expand(5, 6, 3), atol=1e-12)
+    want = 1 - F.cosine_similarity(no, TO.depth_to_normal(b, K), dim=1).mean()
+    assert float(L.compute_normal_consistency_loss(a, b, K=K)) == pytest.approx(float(want), rel=1e-12)
+    assert float(TO.compute_normal_consistency_loss(a, b, K)) == pytest.approx(float(want), rel=1e-12)
+    assert want.shape == () and F.cosine_similarity(no, no, dim=1).shape == (H, 3)
+    d, gt = a[None, ..., None].clone().requires_grad_(), b[None, ..., None]
+    cfg = TrackerConfig(depth_lambda=0.7, normal_lambda=0.1)
+    total, dl, sl = PoseTracker(cfg).tracking_loss(d, gt, K)
+    t_o, dl_o, sl_o = TO.tracking_loss(d, gt, 0.7, 0.1, K)
+    m = (a != 0).double()
+    nl = TO.compute_normal_consistency_loss(a * m, b * m, K)
+    assert float(total.detach()) == pytest.approx(float((0.7 * dl_o + 0.2 * sl_o + 0.1 * nl).detach()), rel=1e-12)
+    assert float(total.detach()) == pytest.approx(float(t_o.detach()), rel=1e-12)
+    total.backward()
+    assert torch.isfinite(d.grad).all() and float(d.grad.abs().max()) > 0
+
+
 def test_geometry_mirror_on_cpu(monkeypatch):
     from gsplatloc_amd.my_gsplat import geometry as Geo
 

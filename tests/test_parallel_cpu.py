@@ -96,6 +96,34 @@ def test_strip_losses_and_gradients_add_up_single_process():
         assert torch.allclose(gs, g, rtol=1e-9, atol=1e-12 * float(g.abs().max()))
 
 
+def test_strip_shares_of_the_normal_term_add_up():
+    """The switched-off normal-consistency term is a mean of row-wise cosines: a rank owns its rows' cosines, and the
+    shares (value and depth gradient) add up to the single-GPU term."""
+    from gsplatloc_amd.synthetic import replica_intrinsics
+    g = torch.Generator().manual_seed(4)
+    H, W = 70, 40
+    K = replica_intrinsics(W, H, dtype=torch.float64)
+    gt = (torch.rand(1, H, W, 1, generator=g, dtype=torch.float64) * 2 + 1)
+    depth0 = gt + 0.05 * torch.randn(1, H, W, 1, generator=g, dtype=torch.float64)
+    depth0[:, 20:24, 5:12] = 0.0
+    d = depth0.clone().requires_grad_()
+    total, _, _ = T.tracking_loss(d, gt, 0.7, 0.1, K)
+    total.backward()
+    th = math.ceil(H / 16)
+    for world in (2, 3):
+        per = math.ceil(th / world)
+        acc, gacc = 0.0, torch.zeros_like(depth0)
+        for rank in range(world):
+            rows = (min(rank * per, th), min((rank + 1) * per, th))
+            dr = depth0.clone().requires_grad_()
+            share, _, _ = strip_tracking_loss(dr, gt, rows, H, 0.7, 0.1, K=K)
+            share.backward()
+            acc += float(share)
+            gacc += dr.grad
+        assert acc == pytest.approx(float(total), rel=1e-12)
+        assert torch.allclose(gacc, d.grad, rtol=1e-9, atol=1e-14)
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
