@@ -13,6 +13,7 @@ Mirrors what /root/reference/src/my_gsplat/gs_trainer_total.py:97-152 does per i
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -22,6 +23,7 @@ from ._lib import check, current_stream, load_library, ptr
 from .fused import _MODES, MAX_STRIP_TILES, alloc_records, tile_n_bits
 
 
+BIN_BYTES_MAX = 2 << 30  # per-tile key bins larger than this in total: stay with two-pass binning
 TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
 
 
@@ -89,7 +91,9 @@ class RenderContext:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
         self.capacity = 0
         self.tiny = False
-        self.flags = torch.zeros(4, dtype=i32, device=dev)  # [0] a splat outgrew the tiny backward (sticky, device-set)
+        # device-set, sticky: [0] a splat outgrew the tiny backward, [1] a tile outgrew its bin, [2] that tile's size
+        self.flags = torch.zeros(4, dtype=i32, device=dev)
+        self.bins, self.bin_cap = None, 0
         self.trec = self.vcT = None
         self.keys = self.flatten_ids = None
         if capacity is not None:
@@ -105,25 +109,49 @@ class RenderContext:
             self.vrow = torch.zeros(self.capacity, 16, dtype=torch.float32, device=self.device)
 
     def calibrate(self, means, quats, scales, opacities, colors, viewmat, K, headroom: float = 1.3) -> int:
-        """One synchronising projection pass to size the intersection buffers."""
+        """One synchronising projection pass to size the intersection buffers and the per-tile bins."""
+        self.bins, self.bin_cap = None, 0  # two-pass binning for this measuring pass
         self._project(means, quats, scales, opacities, colors, viewmat, K)
         n = int(self.n_is.item())
         self._alloc_isects(int(n * headroom) + 1024)
+        longest = int((self.offs[1:] - self.offs[:-1]).max()) if self.n_tiles else 0
+        self._alloc_bins(int(longest * max(headroom, 1.5)) + 64)
         self._choose_backward()
         return n
+
+    def _alloc_bins(self, bin_cap: int) -> None:
+        """Fixed-capacity per-tile key bins: the projection kernel then bins directly (no scatter pass, no counter
+        clearing launch).  Skipped -- two-pass binning stays -- when one tile is so long that bins for every tile
+        would not be worth their memory (BIN_BYTES_MAX)."""
+        self.flags[1:3] = 0
+        if self.n_tiles * bin_cap * 8 > BIN_BYTES_MAX or os.environ.get("GSLOC_BINNING", "direct") == "two-pass":
+            self.bins, self.bin_cap = None, 0
+            return
+        self.bin_cap = int(bin_cap)
+        self.bins = torch.zeros(self.n_tiles * self.bin_cap, dtype=torch.int64, device=self.device)
+        self.ws.zero_()  # the binned projection relies on cleared tile counters (it leaves them cleared)
+
+    def bins_overflowed(self) -> int:
+        """Host sync: 0, or the length of the longest tile list that did not fit its bin since the last calibration."""
+        if self.bins is None:
+            return 0
+        f = self.flags.tolist()
+        return int(f[2]) if f[1] else 0
+
+    def grow_bins(self, longest: int) -> None:
+        self._alloc_bins(int(longest * 1.5) + 64)
 
     def _choose_backward(self) -> None:
         """Tiny-splat backward (per-splat 4x4 record slabs, no reduction, no atomics) when no splat reaches
         more than 4x4 pixel centres (r_cull < 2 px) -- GsplatLoc's as-coded scales; otherwise the general
         compositing backward.  GSLOC_BWD=general disables it (dev switch)."""
-        import os
         r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
         want = os.environ.get("GSLOC_BWD", "auto") != "general" and r_max < TINY_RCULL_MAX and self.Qh is None
         if want and self.trec is None:
             self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
             self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
         self.tiny = want
-        self.flags.zero_()
+        self.flags[0] = 0
 
     def tiny_overflowed(self) -> bool:
         """Host sync: did a splat outgrow the tiny backward since the last calibration?  (The kernel raises the
@@ -133,7 +161,7 @@ class RenderContext:
     def use_general_backward(self) -> None:
         """Recovery after tiny_overflowed(): switch this context to the general compositing backward."""
         self.tiny = False
-        self.flags.zero_()
+        self.flags[0] = 0
 
     def check_capacity(self) -> int:
         """Host sync: intersections of the last forward; raises if they did not fit (or if a splat outgrew the
@@ -143,6 +171,8 @@ class RenderContext:
             raise RuntimeError(f"intersection capacity exceeded ({n} > {self.capacity}); call calibrate() again")
         if self.tiny_overflowed():
             raise RuntimeError("a splat outgrew the tiny-splat backward (r_cull >= 2 px); call calibrate() again")
+        if self.bins_overflowed():
+            raise RuntimeError(f"a tile list outgrew its bin ({self.bins_overflowed()} > {self.bin_cap}); call calibrate() again")
         return n
 
     # ------------------------------------------------------------------ stages (one C-ABI call each)
@@ -152,13 +182,14 @@ class RenderContext:
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, self.near, self.far,
             self.radius_clip, int(self.antialiased), self.tw, self.th, self.ty0, self.ty1, ptr(self.radii),
             ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), ptr(self.comps), None, ptr(self.offs), ptr(self.n_is),
-            ptr(self.ws), self.ws_bytes, ptr(self.Qh), current_stream()), "gsl_fused_project")
+            ptr(self.ws), self.ws_bytes, ptr(self.Qh), ptr(self.bins), self.bin_cap, ptr(self.flags),
+            current_stream()), "gsl_fused_project")
 
     def _bin(self) -> None:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
                                      ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, int(self.deterministic),
-                                     current_stream()), "gsl_fused_bin")
+                                     ptr(self.bins), self.bin_cap, current_stream()), "gsl_fused_bin")
 
     def _raster_fwd(self) -> None:
         check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,

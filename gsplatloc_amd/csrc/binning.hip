@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
                                                    long long capacity, uint64_t* __restrict__ keys,
                                                    int32_t* __restrict__ flatten_ids,
                                                    int64_t* __restrict__ isect_ids, int64_t cam_enc,
-                                                   int write_sorted_keys) {
+                                                   int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
   int t = tile_begin + blockIdx.x;
   long long s = tile_offsets[t], e = tile_offsets[t + 1];
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
   if (s >= e) return;
   int n = (int)(e - s);
   int tid = threadIdx.x;
-  uint64_t* src = keys + s;
+  // unsorted keys of the tile: its span of the packed key array, or its fixed-capacity bin (binned projection)
+  uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
+  if (bins && n > bin_cap) n = bin_cap;
   if (n <= GSL_SORT_LDS_CAP) {
     for (int i = tid; i < n; i += 256) skeys[i] = src[i];
     __syncthreads();
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
       uint64_t k = skeys[i];
       flatten_ids[s + i] = (int32_t)(uint32_t)k;
       if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
-      if (write_sorted_keys) src[i] = k;  // (depth bits, id) in list order: the deterministic backward searches them
+      if (write_sorted_keys) keys[s + i] = k;  // (depth bits, id) in list order: the deterministic backward searches them
     }
   } else {
     bitonic_sort_long(src, n, skeys, tid);  // rare: huge tile list, sorted in place block-wise
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
       uint64_t k = src[i];
       flatten_ids[s + i] = (int32_t)(uint32_t)k;
       if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
+      if (write_sorted_keys && bins) keys[s + i] = k;
     }
   }
 }
@@ -501,20 +504,22 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, 0);
+                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, 0, (uint64_t*)nullptr, 0);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
 
-// gsl_tile_sort that can also leave the sorted (depth bits, id) keys in sort_keys (internal: gsl_fused_bin)
+// gsl_tile_sort that can also leave the sorted (depth bits, id) keys in sort_keys and read the unsorted keys from
+// fixed-capacity per-tile bins instead of sort_keys (internal: gsl_fused_bin)
 extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
-                                  int write_sorted_keys, void* stream) {
+                                  int write_sorted_keys, uint64_t* bins, int bin_cap, void* stream) {
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, write_sorted_keys);
+                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, write_sorted_keys,
+                     bins, bin_cap);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -50,7 +50,10 @@ __device__ __forceinline__ void cam_inverse(const Cam& cam, M3& Ri, float cp[3])
 // ------------------------------------------------------------------------------------------------
 // Forward 1: projection + colour + pack + tile histogram.
 // ------------------------------------------------------------------------------------------------
-template <bool RGB>
+// BINNED: the kernel also reserves each intersection's slot in its tile's fixed-capacity bin (one returning atomic per
+// distinct tile per workgroup, ranks inside the workgroup from LDS) and writes the (depth bits | id) key there: the
+// separate scatter pass and its second read of the records disappear.  tile_counts ends up holding the tile sizes.
+template <bool RGB, bool BINNED>
 __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* __restrict__ opacities, const float* __restrict__ colors, int sh_degree, int K_sh,
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     float far_plane, float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
     int32_t* __restrict__ radii, float4* __restrict__ Q0, float4* __restrict__ Q1, float4* __restrict__ Q2,
     float* __restrict__ comps, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts,
-    uint4* __restrict__ Qh) {
+    uint4* __restrict__ Qh, uint64_t* __restrict__ bins, int bin_cap) {
   extern __shared__ int s_hist[];
   int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
   for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) s_hist[k] = 0;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
   int i = blockIdx.x * GSL_F_BIN_THREADS + threadIdx.x;
   Cam cam = load_cam(V, Kmat);
   int xmin = 0, ymin = 0, xmax = 0, ymax = 0;
+  uint64_t key = 0;
   if (i < N) {
     ProjMid p;
     float q[4], s[3];
@@ -136,22 +140,49 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
       ymin = max(ymin, ty0);
       ymax = min(ymax, ty1);
       if (ymax < ymin) ymax = ymin;
+      key = ((uint64_t)__float_as_uint(o0.z) << 32) | (uint32_t)i;
     }
     if (tiles_per_gauss) tiles_per_gauss[i] = (xmax - xmin) * (ymax - ymin);
   }
   for (int y = ymin; y < ymax; ++y)
     for (int x = xmin; x < xmax; ++x) atomicAdd(&s_hist[y * tile_w + x - tbase], 1);
   __syncthreads();
-  for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) {
-    int c = s_hist[k];
-    if (c) atomicAdd(&tile_counts[tbase + k], c);
+  if (!BINNED) {
+    for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) {
+      int c = s_hist[k];
+      if (c) atomicAdd(&tile_counts[tbase + k], c);
+    }
+    return;
   }
+  // all of a thread's returning atomics are issued before the first result is consumed
+  int res[GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS];
+#pragma unroll
+  for (int u = 0; u < GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS; ++u) {
+    int k = threadIdx.x + u * GSL_F_BIN_THREADS;
+    int c = (k < nst) ? s_hist[k] : 0;
+    res[u] = c ? atomicAdd(&tile_counts[tbase + k], c) : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS; ++u) {
+    int k = threadIdx.x + u * GSL_F_BIN_THREADS;
+    if (k < nst && s_hist[k]) s_hist[k] = res[u];  // first slot of this workgroup's span; ranks count up from it
+  }
+  __syncthreads();
+  for (int y = ymin; y < ymax; ++y)
+    for (int x = xmin; x < xmax; ++x) {
+      int lt = y * tile_w + x - tbase;
+      int slot = atomicAdd(&s_hist[lt], 1);
+      if (slot < bin_cap) bins[(size_t)(tbase + lt) * (size_t)bin_cap + slot] = key;
+    }
 }
 
-// Exclusive scan of tile counts (single workgroup) -> offsets[n+1], total, zeroed cursors.
-__global__ __launch_bounds__(1024) void k_ftile_scan(const int32_t* __restrict__ counts, int n,
+// Exclusive scan of tile counts (single workgroup) -> offsets[n+1], total, zeroed cursors.  The counts are cleared
+// after they are read (the next projection accumulates into them again).  bin_cap > 0: a tile keeps at most bin_cap
+// entries (what its bin holds); a larger count raises flags[1] and leaves the largest count seen in flags[2].
+__global__ __launch_bounds__(1024) void k_ftile_scan(int32_t* __restrict__ counts, int n,
                                                      int32_t* __restrict__ offsets, int32_t* __restrict__ n_isects,
-                                                     int32_t* __restrict__ cursors) {
+                                                     int32_t* __restrict__ cursors, int bin_cap,
+                                                     int32_t* __restrict__ flags) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -160,6 +191,11 @@ __global__ __launch_bounds__(1024) void k_ftile_scan(const int32_t* __restrict__
   for (int base = 0; base < n; base += 1024) {
     int i = base + tid;
     int v = (i < n) ? counts[i] : 0;
+    if (i < n) counts[i] = 0;
+    if (bin_cap > 0 && v > bin_cap) {
+      if (flags) { flags[1] = 1; atomicMax(&flags[2], v); }
+      v = bin_cap;
+    }
     int x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -838,7 +874,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
                                  float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
                                  int32_t* radii, float* Q0, float* Q1, float* Q2, float* compensations,
                                  int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
-                                 size_t ws_bytes, void* Qh, void* stream) {
+                                 size_t ws_bytes, void* Qh, void* bins, int bin_cap, int32_t* flags, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
@@ -850,26 +886,27 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
   if (Q2 && sh_degree >= 0 && (sh_degree > 3 || K_sh < (sh_degree + 1) * (sh_degree + 1))) return GSL_ERR_BAD_ARG;
   if (antialiased && !compensations) return GSL_ERR_BAD_ARG;
   if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
+  if (bins && bin_cap <= 0) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int32_t* counts = (int32_t*)ws;
   int32_t* cursors = counts + n_tiles;
-  if (gsl::zero_u32(counts, (size_t)n_tiles, st) != GSL_OK) return GSL_ERR_HIP;
+  // binned mode relies on the scan leaving the counters cleared (ws zero-filled once by the caller): no clearing launch
+  if (!bins && gsl::zero_u32(counts, (size_t)n_tiles, st) != GSL_OK) return GSL_ERR_HIP;
   if (N > 0) {
     dim3 grid((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), block(GSL_F_BIN_THREADS);
     size_t lds = (size_t)(nst > 0 ? nst : 1) * sizeof(int);
-    if (Q2)
-      hipLaunchKernelGGL(gsl::k_fproject<true>, grid, block, lds, st, means, quats, scales, opacities, colors,
-                         sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,
-                         antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,
-                         compensations, tiles_per_gauss, counts, (uint4*)Qh);
-    else
-      hipLaunchKernelGGL(gsl::k_fproject<false>, grid, block, lds, st, means, quats, scales, opacities, colors,
-                         sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,
-                         antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,
-                         compensations, tiles_per_gauss, counts, (uint4*)Qh);
+#define CALL_P(RGBV, BINV)                                                                                            \
+  hipLaunchKernelGGL((gsl::k_fproject<RGBV, BINV>), grid, block, lds, st, means, quats, scales, opacities, colors,    \
+                     sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,        \
+                     antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,             \
+                     compensations, tiles_per_gauss, counts, (uint4*)Qh, (uint64_t*)bins, bin_cap)
+    if (Q2) { if (bins) CALL_P(true, true); else CALL_P(true, false); }
+    else { if (bins) CALL_P(false, true); else CALL_P(false, false); }
+#undef CALL_P
     GSL_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(gsl::k_ftile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors);
+  hipLaunchKernelGGL(gsl::k_ftile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors,
+                     bins ? bin_cap : 0, flags);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -877,12 +914,12 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
 // defined in binning.hip
 extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
-                                  int write_sorted_keys, void* stream);
+                                  int write_sorted_keys, uint64_t* bins, int bin_cap, void* stream);
 
 extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0, int ty1,
                              int tile_n_bits, const int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
                              int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes,
-                             int write_sorted_keys, void* stream) {
+                             int write_sorted_keys, void* bins, int bin_cap, void* stream) {
   if (N < 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0)
     return GSL_ERR_BAD_ARG;
   int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
@@ -890,6 +927,11 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
   if (N == 0 || capacity == 0 || nst == 0) return GSL_OK;
   if (!Q0 || !radii || !sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
+  if (bins) {  // gsl_fused_project already put every key into its tile's bin
+    if (bin_cap <= 0) return GSL_ERR_BAD_ARG;
+    return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
+                              write_sorted_keys, (uint64_t*)bins, bin_cap, stream);
+  }
   hipStream_t st = (hipStream_t)stream;
   int32_t* cursors = (int32_t*)ws + n_tiles;
   hipLaunchKernelGGL(gsl::k_fscatter, dim3((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), dim3(GSL_F_BIN_THREADS),
@@ -897,7 +939,7 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
                      tile_offsets, cursors, (long long)capacity, sort_keys);
   GSL_CHECK_LAUNCH();
   return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
-                            write_sorted_keys, stream);
+                            write_sorted_keys, nullptr, 0, stream);
 }
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \

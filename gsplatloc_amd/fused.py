@@ -61,7 +61,7 @@ class _FusedRasterization(torch.autograd.Function):
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rgb else None, sh_degree, K_sh,
             ptr(viewmat), ptr(K), N, W, H, eps2d, near, far, radius_clip, int(antialiased), tw, th, ty0, ty1,
             ptr(radii), ptr(Q0), ptr(Q1), ptr(Q2), ptr(comps), ptr(tpg), ptr(offs), ptr(n_is), ptr(ws), ws_bytes,
-            None, st), "gsl_fused_project")
+            None, None, 0, None, st), "gsl_fused_project")  # two-pass binning: tile sizes are not known in advance
         n_isects = int(n_is.item())  # output sizes depend on it (gsplat syncs at the same point)
         cap = max(n_isects, 1)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -69,8 +69,8 @@ class _FusedRasterization(torch.autograd.Function):
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_isect_ids else None
         check(lib.gsl_fused_bin(ptr(Q0), ptr(radii), N, tw, th, ty0, ty1, tile_n_bits(n_tiles), ptr(offs), n_isects,
                                 ptr(keys), ptr(flatten_ids) if n_isects else None,
-                                ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, 0, st),
-              "gsl_fused_bin")
+                                ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, 0, None, 0,
+                                st), "gsl_fused_bin")
         render = torch.zeros(H, W, D, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, D, dtype=f32, device=dev)
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \

@@ -225,9 +225,10 @@ class GraphTracker:
                 for _ in range(n):
                     self._iteration()
                 done += n
-                # the only host sync: stopped flag, intersection count, tiny-backward overflow flag
+                # the only host sync: stopped flag, intersection count, overflow flags (tiny backward, tile bins)
                 stopped, n_is, tiny_over = int(self.pose_i[2].item()), int(self.rc.n_is.item()), self.rc.tiny_overflowed()
-                if n_is > self.rc.capacity or tiny_over:
+                bin_over = self.rc.bins_overflowed()
+                if n_is > self.rc.capacity or tiny_over or bin_over:
                     redo = True
                     break
                 if stopped:
@@ -237,6 +238,8 @@ class GraphTracker:
             # recover: iterations since the last poll ran on truncated lists or a dropped gradient
             if tiny_over:
                 self.rc.use_general_backward()
+            if bin_over:
+                self.rc.grow_bins(bin_over)
             if n_is > self.rc.capacity:
                 self.headroom *= 1.5
                 self.rc._alloc_isects(int(n_is * self.headroom) + 1024)

@@ -404,6 +404,63 @@ def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
             mostly_close(out["auto"][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
 
 
+def test_binned_projection_gives_the_lists_of_two_pass_binning():
+    """RenderContext bins directly from the projection kernel once calibrate() knows the tile sizes (no scatter pass);
+    the sorted lists, offsets, render and gradients are those of the count -> scan -> scatter path, bit for bit
+    (integer work) -- also for a strip, for the deterministic mode's sorted keys, and when a pose change makes the
+    lists longer than at calibration.  A tile that outgrows its bin is flagged, never silently truncated."""
+    _gpu()
+    from gsplatloc_amd.context import RenderContext
+    W, H, N = 260, 200, 40000
+    sc = _scene32(N, W, H, sigma_px=1.3, opacity=(0.3, 1.0))
+    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+    ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
+    V0 = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
+    V1 = torch.linalg.inv(small_pose(0.8, 0.02, dtype=torch.float32)).to(DEV).contiguous()
+    K = sc["K"].to(DEV).contiguous()
+    th = (H + 15) // 16
+    v = torch.randn(H, W, 4, generator=torch.Generator().manual_seed(2)).to(DEV)
+    va = torch.zeros(H, W, 1, device=DEV)
+    for rows, det in ((None, False), ((3, 9), False), (None, True)):
+        rc = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, tile_rows=rows, deterministic=det)
+        rc.calibrate(*ins, V0, K)
+        assert rc.bins is not None and rc.bin_cap > 0
+        got = {}
+        for name, V in (("calibrated pose", V0), ("moved pose", V1)):
+            for binned in (True, False):
+                if not binned:
+                    keep = (rc.bins, rc.bin_cap)
+                    rc.bins, rc.bin_cap = None, 0
+                rc.forward(*ins, V, K)
+                g = rc.backward(v, va)
+                n = rc.check_capacity()
+                got[binned] = dict(n=n, offs=rc.offs.clone(), ids=rc.flatten_ids[:n].clone(), render=rc.render.clone(),
+                                   keys=rc.keys[:n].clone() if det else None,
+                                   vm=g["viewmat"].clone(), means=g["means"].clone())
+                if not binned:
+                    rc.bins, rc.bin_cap = keep
+            a, b = got[True], got[False]
+            assert a["n"] == b["n"] > 0 and torch.equal(a["offs"], b["offs"]) and torch.equal(a["ids"], b["ids"]), name
+            assert torch.equal(a["render"], b["render"])
+            if det:
+                assert torch.equal(a["keys"], b["keys"])
+                assert torch.equal(a["vm"], b["vm"]) and torch.equal(a["means"], b["means"])
+            else:
+                assert float((a["vm"] - b["vm"]).abs().max()) <= 1e-5 * float(b["vm"].abs().max())
+        # shrink the bins below the longest list: flagged with that length, and the lists hold what fitted
+        longest = int((rc.offs[1:] - rc.offs[:-1]).max())
+        rc._alloc_bins(longest // 2)
+        rc.forward(*ins, V1, K)
+        assert rc.bins_overflowed() == longest
+        assert int((rc.offs[1:] - rc.offs[:-1]).max()) == longest // 2
+        with pytest.raises(RuntimeError, match="outgrew its bin"):
+            rc.check_capacity()
+        rc.grow_bins(longest)
+        rc.forward(*ins, V1, K)
+        assert rc.bins_overflowed() == 0 and rc.check_capacity() == got[False]["n"]
+        assert torch.equal(rc.flatten_ids[:got[False]["n"]], got[False]["ids"])
+
+
 @pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB", True)])
 def test_deterministic_backward_is_bit_reproducible(mode, full):
     """RenderContext(deterministic=True): no float atomics in the backward (per-wave moment rows summed in wave order,
