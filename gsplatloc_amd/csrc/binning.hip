@@ -13,7 +13,7 @@
 
 namespace gsl {
 
-#define GSL_SORT_LDS_CAP 4096  // intersections per tile sorted in LDS (32 KiB); longer lists sort in global memory
+#define GSL_SORT_LDS_CAP 1024  // keys per LDS block of the long-list sort (8 KiB: no occupancy cost for the wave sorts)
 
 // Per-wave merged atomic add of 1 on ctr[key]: lanes holding the same key elect a leader.
 // Returns the position (old value + rank among equal lanes) for `active` lanes.
@@ -313,8 +313,8 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
 // Lists longer than the LDS capacity (a pile of splats in one tile: e.g. the invalid pixels of a TUM depth frame,
 // which all sit at the previous camera's origin).  Same network, run block-wise: every stage k <= CAP is the LDS sort
 // of one aligned CAP-key block; of a stage k > CAP only the sub-steps at distance >= CAP touch global memory, the
-// remaining log2(CAP) sub-steps stay inside aligned blocks and run in LDS.  For n = 24 k: 6 global sub-steps instead
-// of 120.
+// remaining log2(CAP) sub-steps stay inside aligned blocks and run in LDS.  For n = 24 k: 15 global sub-steps
+// instead of 120.
 __device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* lds, int tid) {
   constexpr int CAP = GSL_SORT_LDS_CAP;
   int nblk = (n + CAP - 1) / CAP;
@@ -344,34 +344,142 @@ __device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* 
   }
 }
 
-// One workgroup per tile: sort the tile's bucket, write flatten_ids (+ gsplat-style isect_ids).
+// ------------------------------------------------------------------------------------------------
+// Per-tile sort, one WAVE per tile: the same ascending bitonic network, with the keys held in registers.
+// Element e = lane * KPT + r lives in register r of lane `lane` (KPT = 4 .. 32 keys per lane, P = 64 KPT >= n, padded
+// with +inf).  Comparator distances below KPT are register-to-register (no data movement at all: 34 of the 55
+// sub-steps at P = 1024), the others exchange through the cross-lane network (ds_bpermute, no memory), and nothing
+// needs a barrier or LDS.  Measured against the LDS version it replaces: see DESIGN.md.  Lists longer than 2048
+// entries (a pile of splats in one tile) are sorted by the whole workgroup block-wise, bitonic_sort_long.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = (unsigned)__shfl_xor((int)lo, mask, 64);
+  hi = (unsigned)__shfl_xor((int)hi, mask, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {  // a <- min, b <- max
+  bool sw = a > b;
+  uint64_t t = sw ? b : a;
+  b = sw ? a : b;
+  a = t;
+}
+__device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, bool keep_min) {
+  bool lt = o < a;
+  return (lt == keep_min) ? o : a;
+}
+
+template <int LK>
+__device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane) {
+  constexpr int KPT = 1 << LK;
+  // stages whose blocks fit inside one lane's registers
+#pragma unroll
+  for (int lk = 1; lk <= LK; ++lk) {
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+      int p = r ^ ((1 << lk) - 1);
+      if (r < p) cswap(k[r], k[p]);
+    }
+#pragma unroll
+    for (int lj = lk - 2; lj >= 0; --lj)
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        int p = r ^ (1 << lj);
+        if (r < p) cswap(k[r], k[p]);
+      }
+  }
+  // stages that span 2^tb lanes: the flip pairs (lane, r) with (lane ^ (2^tb - 1), KPT - 1 - r), the half-cleaners
+  // at lane distance 2^b pair equal registers, the rest is register-to-register again
+#pragma unroll 1
+  for (int tb = 1; tb <= 6; ++tb) {
+    int mask = (1 << tb) - 1;
+    bool keep_min = ((lane >> (tb - 1)) & 1) == 0;
+#pragma unroll
+    for (int r = 0; r < KPT / 2; ++r) {
+      uint64_t o_r = shfl_xor_u64(k[KPT - 1 - r], mask);
+      uint64_t o_p = shfl_xor_u64(k[r], mask);
+      k[r] = pick(k[r], o_r, keep_min);
+      k[KPT - 1 - r] = pick(k[KPT - 1 - r], o_p, keep_min);
+    }
+#pragma unroll 1
+    for (int b = tb - 2; b >= 0; --b) {
+      bool km = ((lane >> b) & 1) == 0;
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) k[r] = pick(k[r], shfl_xor_u64(k[r], 1 << b), km);
+    }
+#pragma unroll
+    for (int lj = LK - 1; lj >= 0; --lj)
+#pragma unroll
+      for (int r = 0; r < KPT; ++r) {
+        int p = r ^ (1 << lj);
+        if (r < p) cswap(k[r], k[p]);
+      }
+  }
+}
+
+template <int LK>
+__device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int lane,
+                                               uint64_t* __restrict__ keys_out, int32_t* __restrict__ flatten_ids,
+                                               int64_t* __restrict__ isect_ids, int64_t cam_enc) {
+  constexpr int KPT = 1 << LK;
+  uint64_t k[KPT];
+  int e0 = lane * KPT;
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) k[r] = (e0 + r < n) ? src[e0 + r] : ~0ull;
+  wave_sort_regs<LK>(k, lane);
+#pragma unroll
+  for (int r = 0; r < KPT; ++r)
+    if (e0 + r < n) {
+      uint64_t v = k[r];
+      flatten_ids[s + e0 + r] = (int32_t)(uint32_t)v;
+      if (isect_ids) isect_ids[s + e0 + r] = cam_enc | ((int64_t)t << 32) | (int64_t)(v >> 32);
+      if (keys_out) keys_out[s + e0 + r] = v;
+    }
+}
+
+#define GSL_SORT_WAVE_MAX 2048  // longest list one wave sorts in registers (32 keys per lane)
+
+// Four tiles per 256-thread workgroup, one per wave; write flatten_ids (+ gsplat-style isect_ids, + the sorted keys
+// when the deterministic backward wants them).  The unsorted keys of a tile are its span of `keys`, or its
+// fixed-capacity bin (binned projection).
 __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ tile_offsets, int tile_begin,
-                                                   long long capacity, uint64_t* __restrict__ keys,
-                                                   int32_t* __restrict__ flatten_ids,
+                                                   int n_strip_tiles, long long capacity,
+                                                   uint64_t* __restrict__ keys, int32_t* __restrict__ flatten_ids,
                                                    int64_t* __restrict__ isect_ids, int64_t cam_enc,
                                                    int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
-  int t = tile_begin + blockIdx.x;
-  long long s = tile_offsets[t], e = tile_offsets[t + 1];
-  if (e > capacity) e = capacity;
-  if (s >= e) return;
-  int n = (int)(e - s);
-  int tid = threadIdx.x;
-  // unsorted keys of the tile: its span of the packed key array, or its fixed-capacity bin (binned projection)
-  uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
-  if (bins && n > bin_cap) n = bin_cap;
-  if (n <= GSL_SORT_LDS_CAP) {
-    for (int i = tid; i < n; i += 256) skeys[i] = src[i];
-    __syncthreads();
-    bitonic_sort_lds(skeys, n, tid);
-    for (int i = tid; i < n; i += 256) {
-      uint64_t k = skeys[i];
-      flatten_ids[s + i] = (int32_t)(uint32_t)k;
-      if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
-      if (write_sorted_keys) keys[s + i] = k;  // (depth bits, id) in list order: the deterministic backward searches them
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int local = blockIdx.x * 4 + wv;
+  if (local < n_strip_tiles) {
+    int t = tile_begin + local;
+    long long s = tile_offsets[t], e = tile_offsets[t + 1];
+    if (e > capacity) e = capacity;
+    int n = (int)max(e - s, (long long)0);
+    if (bins && n > bin_cap) n = bin_cap;
+    const uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
+    // sorted keys go to the packed array; in place when that is also the source (every lane has read its keys
+    // into registers before any lane writes)
+    uint64_t* kout = write_sorted_keys ? keys : nullptr;
+    if (n > 0 && n <= GSL_SORT_WAVE_MAX) {
+      if (n <= 256) wave_sort_tile<2>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
+      else if (n <= 512) wave_sort_tile<3>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
+      else if (n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
+      else wave_sort_tile<5>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
     }
-  } else {
-    bitonic_sort_long(src, n, skeys, tid);  // rare: huge tile list, sorted in place block-wise
+  }
+  // rare: lists too long for one wave, sorted in place by the whole workgroup, one after the other
+  for (int q = 0; q < 4; ++q) {
+    int lq = blockIdx.x * 4 + q;
+    if (lq >= n_strip_tiles) break;
+    int t = tile_begin + lq;
+    long long s = tile_offsets[t], e = tile_offsets[t + 1];
+    if (e > capacity) e = capacity;
+    int n = (int)max(e - s, (long long)0);
+    if (bins && n > bin_cap) n = bin_cap;
+    if (n <= GSL_SORT_WAVE_MAX) continue;
+    uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
+    __syncthreads();
+    bitonic_sort_long(src, n, skeys, tid);
     for (int i = tid; i < n; i += 256) {
       uint64_t k = src[i];
       flatten_ids[s + i] = (int32_t)(uint32_t)k;
@@ -503,8 +611,9 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, 0, (uint64_t*)nullptr, 0);
+  hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                     tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, 0,
+                     (uint64_t*)nullptr, 0);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -517,9 +626,9 @@ extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, i
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_tile_sort, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, write_sorted_keys,
-                     bins, bin_cap);
+  hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                     tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
+                     write_sorted_keys, bins, bin_cap);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -141,10 +141,10 @@ def test_binning_multi_camera_and_empty():
     assert off.shape == (2, th, tw) and int(off.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("N", [4097, 8192, 12289, 20000, 70001])
+@pytest.mark.parametrize("N", [200, 256, 257, 700, 1024, 1025, 2048, 2049, 3000, 4097, 8192, 12289, 20000, 70001])
 def test_binning_long_tile_list_uses_global_sort(N):
-    """More intersections in one tile than the LDS sort holds (4096): the block-wise long-list sort, with whole and
-    partial last blocks and 1 to 5 cross-block stages."""
+    """One tile list of every size class of the sort: a wave's registers (4, 8, 16, 32 keys per lane, at and around the
+    class boundaries), and beyond 2048 entries the block-wise long-list sort with whole and partial last blocks."""
     A = _gpu()
     g = torch.Generator().manual_seed(3)
     m2 = (torch.rand(1, N, 2, generator=g) * 14 + 1).float()
