@@ -45,22 +45,24 @@ _SIGNATURES = {
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                      P, P, P, P, P, P, c_int, c_int, P, P, P]),
     "gsl_loss_ws_bytes": (c_size_t, [c_int, c_int]),
+    "gsl_loss_n_partials": (c_int, [c_int, c_int, c_int, c_int]),
     "gsl_tracking_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_size_t,
                                   P]),
     "gsl_pose_init": (c_int, [P, P, P, c_float, c_float, P, P, P]),
     "gsl_normal_ws_bytes": (c_size_t, [c_int, c_int]),
     "gsl_normal_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                                 P, P, P, c_size_t, P]),
-    "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
+    "gsl_fused_viewmat_rows": (P, [P, c_int]),
+    "gsl_pose_step": (c_int, [P, P, P, P, c_int, P, P, c_int, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float,
                               c_float, c_float, c_float, c_float, c_int, c_int, c_int, c_int, P, P, P, P]),
-    "gsl_pack_pose_reduce": (c_int, [P, P, c_int, P, P, P]),
+    "gsl_pack_pose_reduce": (c_int, [P, P, c_int, P, P, P, c_int, P, P, P]),
     "gsl_knn_ws_bytes": (c_size_t, [c_int]),
     "gsl_knn_cells": (c_int, []),
     "gsl_knn_count": (c_int, [P, c_int, P, P, c_size_t, P]),
     "gsl_knn_query": (c_int, [P, c_int, P, P, c_int, P, P, c_size_t, P]),
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P, P, P, P, c_int, c_int,
-                                      c_int, c_int, c_int64, P]),
+                                      c_int, c_int, c_int64, c_int, P]),
     "gsl_tiny_gather": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                     P, P, P, P, P, P, P, c_int, c_int, P, P]),

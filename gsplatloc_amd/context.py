@@ -153,6 +153,10 @@ class RenderContext:
         self.tiny = want
         self.flags[0] = 0
 
+    def viewmat_rows(self) -> Tuple[int, int]:
+        """(device pointer, row count) of the pose-gradient partial rows a backward(reduce_viewmat=False) leaves."""
+        return self.lib.gsl_fused_viewmat_rows(ptr(self.ws), self.n_tiles), (self.N + 255) // 256
+
     def tiny_overflowed(self) -> bool:
         """Host sync: did a splat outgrow the tiny backward since the last calibration?  (The kernel raises the
         sticky device flag instead of dropping the gradient silently.)"""
@@ -212,7 +216,7 @@ class RenderContext:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
                                                 ptr(self.vrow), current_stream()), "gsl_fused_raster_bwd")
 
-    def _project_bwd(self, full: bool) -> None:
+    def _project_bwd(self, full: bool, reduce: bool = True) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
         if self.vrow is not None and not self.tiny:  # deterministic general backward: rows per intersection
             det = (ptr(self.vrow), ptr(self.keys), ptr(self.offs), ptr(self.Q0), self.tw, self.th, self.ty0, self.ty1,
@@ -226,7 +230,7 @@ class RenderContext:
             ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
             ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
             ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
-            self.n_tiles, *det, current_stream()), "gsl_fused_project_bwd")
+            self.n_tiles, *det, int(reduce), current_stream()), "gsl_fused_project_bwd")
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
@@ -240,14 +244,17 @@ class RenderContext:
         self._inputs = (means, quats, scales, opacities, colors, viewmat, K)
         return self.render, self.alphas
 
-    def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None) -> Dict[str, Tensor]:
+    def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None,
+                 reduce_viewmat: bool = True) -> Dict[str, Tensor]:
         """vjp of the last forward.  Returns the context's gradient buffers: always ``viewmat``
-        ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors."""
+        ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors.
+        ``reduce_viewmat=False`` skips the last launch: the pose gradient stays as ``viewmat_rows()`` for
+        gsl_pose_step / gsl_pack_pose_reduce, which sum them in the same fixed order (``viewmat`` is then stale)."""
         assert self._inputs is not None, "forward() first"
         full = self.full_grads if full is None else full
         assert not full or self.full_grads, "context was built with full_grads=False"
         self._raster_bwd(v_render, v_alphas)
-        self._project_bwd(full)
+        self._project_bwd(full, reduce_viewmat)
         out = {"viewmat": self.v_viewmat}
         if full:
             out.update(means=self.v_means, quats=self.v_quats, scales=self.v_scales, opacities=self.v_opacities,
@@ -286,8 +293,8 @@ def pack_pose_reduce(v_viewmat: Tensor, out16: Tensor, loss_partials: Optional[T
     out16[12:14] = the sums of loss_partials[n,2] (or 0), out16[14] = normal_sum (or 0), written by a kernel of the
     library -- no torch op, so a captured iteration holds this library's launches only."""
     n = 0 if loss_partials is None else loss_partials.numel() // 2
-    check(load_library().gsl_pack_pose_reduce(ptr(v_viewmat), ptr(loss_partials), n, ptr(normal_sum), ptr(out16),
-                                              current_stream()), "gsl_pack_pose_reduce")
+    check(load_library().gsl_pack_pose_reduce(ptr(v_viewmat), None, 0, None, None, ptr(loss_partials), n,
+                                              ptr(normal_sum), ptr(out16), current_stream()), "gsl_pack_pose_reduce")
 
 
 def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, full: bool, steps: int = 20) -> Dict:

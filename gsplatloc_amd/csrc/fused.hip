@@ -28,25 +28,6 @@ __device__ __forceinline__ float cull_radius(float ca, float cb, float cc, float
   return sqrtf(inv * fmaxf(ca, cc)) * 1.0001f + 1e-3f;
 }
 
-// Inverse of the rotation block and the camera position -R^-1 t (what torch.inverse(viewmat)[:3,3] is).
-__device__ __forceinline__ void cam_inverse(const Cam& cam, M3& Ri, float cp[3]) {
-  const M3& R = cam.R;
-  float c00 = R(1, 1) * R(2, 2) - R(1, 2) * R(2, 1);
-  float c01 = R(1, 2) * R(2, 0) - R(1, 0) * R(2, 2);
-  float c02 = R(1, 0) * R(2, 1) - R(1, 1) * R(2, 0);
-  float det = R(0, 0) * c00 + R(0, 1) * c01 + R(0, 2) * c02;
-  float id = 1.f / det;
-  Ri(0, 0) = c00 * id; Ri(1, 0) = c01 * id; Ri(2, 0) = c02 * id;
-  Ri(0, 1) = (R(0, 2) * R(2, 1) - R(0, 1) * R(2, 2)) * id;
-  Ri(1, 1) = (R(0, 0) * R(2, 2) - R(0, 2) * R(2, 0)) * id;
-  Ri(2, 1) = (R(0, 1) * R(2, 0) - R(0, 0) * R(2, 1)) * id;
-  Ri(0, 2) = (R(0, 1) * R(1, 2) - R(0, 2) * R(1, 1)) * id;
-  Ri(1, 2) = (R(0, 2) * R(1, 0) - R(0, 0) * R(1, 2)) * id;
-  Ri(2, 2) = (R(0, 0) * R(1, 1) - R(0, 1) * R(1, 0)) * id;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) cp[k] = -(Ri(k, 0) * cam.t[0] + Ri(k, 1) * cam.t[1] + Ri(k, 2) * cam.t[2]);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Forward 1: projection + colour + pack + tile histogram.
 // ------------------------------------------------------------------------------------------------
@@ -827,36 +808,8 @@ __global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict
                                                         float* __restrict__ v_viewmat) {
   __shared__ float red[4][15];
   __shared__ float tot[15];
-  float acc[15];
-#pragma unroll
-  for (int k = 0; k < 15; ++k) acc[k] = 0.f;
-  for (int b = threadIdx.x; b < nb; b += 256)
-#pragma unroll
-    for (int k = 0; k < 15; ++k) acc[k] += partials[(size_t)b * 16 + k];
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 15; ++k) {
-    float s = wave_sum(acc[k]);
-    if (lane == 0) red[wv][k] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < 15) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-    float v = 0.f;
-    if (r < 3) {
-      Cam cam = load_cam(V, Kmat);
-      M3 Ri;
-      float cp[3];
-      cam_inverse(cam, Ri, cp);
-      // w = R^-T v_campos
-      float w = Ri(0, r) * tot[12] + Ri(1, r) * tot[13] + Ri(2, r) * tot[14];
-      if (c < 3) v = tot[r * 3 + c] - w * cp[c];
-      else v = tot[9 + r] - w;
-    }
-    v_viewmat[threadIdx.x] = v;
-  }
+  float v = reduce_viewmat_rows(partials, nb, V, Kmat, red, tot);
+  if (threadIdx.x < 16) v_viewmat[threadIdx.x] = v;
 }
 
 }  // namespace gsl
@@ -866,6 +819,12 @@ extern "C" size_t gsl_fused_ws_bytes(int N, int n_tiles) {
   // [tile_counts n_tiles][cursors n_tiles][partials ceil(N/256)*16 floats]
   size_t nb = ((size_t)(N > 0 ? N : 1) + 255) / 256;
   return (size_t)2 * (size_t)(n_tiles > 0 ? n_tiles : 1) * sizeof(int32_t) + nb * 16 * sizeof(float);
+}
+
+// where gsl_fused_project_bwd leaves the pose-gradient rows inside ws: ceil(N / 256) rows of 16 floats (15 used)
+extern "C" const float* gsl_fused_viewmat_rows(const void* ws, int n_tiles) {
+  if (!ws || n_tiles <= 0) return nullptr;
+  return (const float*)((const int32_t*)ws + 2 * (size_t)n_tiles);
 }
 
 extern "C" int gsl_fused_project(const float* means, const float* quats, const float* scales, const float* opacities,
@@ -997,8 +956,10 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
                                      float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                                      float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
                                      const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0,
-                                     int tile_w, int tile_h, int ty0, int ty1, int64_t capacity, void* stream) {
+                                     int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
+                                     int reduce_viewmat, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || n_tiles <= 0) return GSL_ERR_BAD_ARG;
+  if (reduce_viewmat && !v_viewmat) return GSL_ERR_BAD_ARG;
   if (channels != 1 && channels != 3 && channels != 4) return GSL_ERR_BAD_ARG;
   bool full = v_means != nullptr;
   if (full != (v_quats != nullptr) || full != (v_scales != nullptr) || full != (v_opacities != nullptr))
@@ -1007,7 +968,7 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
   if (antialiased && !compensations) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) {
-    if (v_viewmat && gsl::zero_u32(v_viewmat, 16, st) != GSL_OK) return GSL_ERR_HIP;
+    if (reduce_viewmat && gsl::zero_u32(v_viewmat, 16, st) != GSL_OK) return GSL_ERR_HIP;
     return GSL_OK;
   }
   if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !Q1) return GSL_ERR_BAD_ARG;
@@ -1017,7 +978,8 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     return GSL_ERR_BAD_ARG;
   if (channels >= 3 && !colors) return GSL_ERR_BAD_ARG;
   if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
-  float* partials = v_viewmat ? (float*)((int32_t*)ws + 2 * (size_t)n_tiles) : nullptr;
+  // one row of 15 sums per workgroup; reduce_viewmat = 0 leaves them for gsl_pose_step / gsl_pack_pose_reduce
+  float* partials = (float*)((int32_t*)ws + 2 * (size_t)n_tiles);
   int grid = (N + 255) / 256;
 #define CALL_PB(FF, DD)                                                                                          \
   hipLaunchKernelGGL((gsl::k_fproject_bwd<FF, DD>), dim3(grid), dim3(256), 0, st, means, quats, scales, opacities, \
@@ -1032,7 +994,7 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
   }
 #undef CALL_PB
   GSL_CHECK_LAUNCH();
-  if (v_viewmat) {
+  if (reduce_viewmat) {
     hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
     GSL_CHECK_LAUNCH();
   }

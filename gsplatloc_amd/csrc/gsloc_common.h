@@ -155,6 +155,64 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Inverse of the rotation block and the camera position -R^-1 t (what torch.inverse(viewmat)[:3,3] is).
+__device__ __forceinline__ void cam_inverse(const Cam& cam, M3& Ri, float cp[3]) {
+  const M3& R = cam.R;
+  float c00 = R(1, 1) * R(2, 2) - R(1, 2) * R(2, 1);
+  float c01 = R(1, 2) * R(2, 0) - R(1, 0) * R(2, 2);
+  float c02 = R(1, 0) * R(2, 1) - R(1, 1) * R(2, 0);
+  float det = R(0, 0) * c00 + R(0, 1) * c01 + R(0, 2) * c02;
+  float id = 1.f / det;
+  Ri(0, 0) = c00 * id; Ri(1, 0) = c01 * id; Ri(2, 0) = c02 * id;
+  Ri(0, 1) = (R(0, 2) * R(2, 1) - R(0, 1) * R(2, 2)) * id;
+  Ri(1, 1) = (R(0, 0) * R(2, 2) - R(0, 2) * R(2, 0)) * id;
+  Ri(2, 1) = (R(0, 1) * R(2, 0) - R(0, 0) * R(2, 1)) * id;
+  Ri(0, 2) = (R(0, 1) * R(1, 2) - R(0, 2) * R(1, 1)) * id;
+  Ri(1, 2) = (R(0, 2) * R(1, 0) - R(0, 0) * R(1, 2)) * id;
+  Ri(2, 2) = (R(0, 0) * R(1, 1) - R(0, 1) * R(1, 0)) * id;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cp[k] = -(Ri(k, 0) * cam.t[0] + Ri(k, 1) * cam.t[1] + Ri(k, 2) * cam.t[2]);
+}
+
+// The pose gradient leaves the projection backward as one row of 15 sums per workgroup
+// ([v_R 9 | v_t 3 | v_campos 3], 16 floats apart).  Fixed-order sum of the rows by a 256-thread workgroup, chain of
+// the SH view direction through the camera position (campos = -R^-1 t): thread t < 16 returns v_viewmat[t]
+// (row 3 = 0: that row is constant).  Used by k_freduce_viewmat and, to save its launch, by the tracker's pose step.
+__device__ __forceinline__ float reduce_viewmat_rows(const float* __restrict__ partials, int nb,
+                                                     const float* __restrict__ V, const float* __restrict__ Kmat,
+                                                     float (*red)[15], float* tot) {
+  float acc[15];
+#pragma unroll
+  for (int k = 0; k < 15; ++k) acc[k] = 0.f;
+  for (int b = threadIdx.x; b < nb; b += 256)
+#pragma unroll
+    for (int k = 0; k < 15; ++k) acc[k] += partials[(size_t)b * 16 + k];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    float s = wave_sum(acc[k]);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  __syncthreads();
+  float v = 0.f;
+  if (threadIdx.x < 16) {
+    int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    if (r < 3) {
+      Cam cam = load_cam(V, Kmat);
+      M3 Ri;
+      float cp[3];
+      cam_inverse(cam, Ri, cp);
+      // w = R^-T v_campos
+      float w = Ri(0, r) * tot[12] + Ri(1, r) * tot[13] + Ri(2, r) * tot[14];
+      if (c < 3) v = tot[r * 3 + c] - w * cp[c];
+      else v = tot[9 + r] - w;
+    }
+  }
+  return v;
+}
+
 // Tile rectangle of a projected Gaussian: [xmin,xmax) x [ymin,ymax) in tiles.
 __device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tile_size, int tile_w,
                                           int tile_h, int& xmin, int& ymin, int& xmax, int& ymax) {

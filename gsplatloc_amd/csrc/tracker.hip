@@ -24,82 +24,97 @@ __device__ __forceinline__ void sobel_at(F img, int i, int j, int H, int W, floa
   gy = ((p[2][0] - p[0][0]) + 2.f * (p[2][1] - p[0][1]) + (p[2][2] - p[0][2])) * 0.125f;
 }
 
-// Stage 1: per owned pixel the L1 terms and the edge-loss weights wx = s*gx/S, wy = s*gy/S
-// (s = sign(S_d - S_g)).  render is [H,W,D], depth = channel D-1.  Rows [r0,r1) are owned (loss terms),
-// rows [h0,h1) carry valid depth (owned + halo).  partial[block] = (sum|a-b|, sum|Sa-Sb|).
-__global__ __launch_bounds__(256) void k_loss_stage1(const float* __restrict__ render, int D,
-                                                     const float* __restrict__ gt, int W, int H, int r0, int r1,
-                                                     float* __restrict__ wxy, float* __restrict__ partial) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  int nown = (r1 - r0) * W;
-  float l1 = 0.f, le = 0.f;
-  if (idx < nown) {
-    int i = r0 + idx / W, j = idx - (idx / W) * W;
-    auto A = [&](int ii, int jj) { return render[((size_t)ii * W + jj) * D + (D - 1)]; };            // d * m == d
-    auto B = [&](int ii, int jj) {
-      float d = render[((size_t)ii * W + jj) * D + (D - 1)];
-      return d != 0.f ? gt[(size_t)ii * W + jj] : 0.f;                                                // g * m
-    };
-    float a = A(i, j), b = B(i, j);
-    l1 = fabsf(a - b);
-    float gxa, gya, gxb, gyb;
-    sobel_at(A, i, j, H, W, gxa, gya);
-    sobel_at(B, i, j, H, W, gxb, gyb);
-    float Sa = sqrtf(gxa * gxa + gya * gya + 1e-6f), Sb = sqrtf(gxb * gxb + gyb * gyb + 1e-6f);
-    le = fabsf(Sa - Sb);
-    float s = (Sa > Sb) ? 1.f : ((Sa < Sb) ? -1.f : 0.f);
-    wxy[2 * ((size_t)i * W + j)] = s * gxa / Sa;
-    wxy[2 * ((size_t)i * W + j) + 1] = s * gya / Sa;
-  }
+// One workgroup per 16x16 pixel block of rows [h0,h1) (owned rows [r0,r1) plus the one-row halo whose depth the owned
+// rows' Sobel reads).  The block's depth values with a two-pixel apron go through LDS once; the edge-loss weights
+// wx = s*gx/S, wy = s*gy/S (s = sign(S_d - S_g)) of the block and its one-pixel ring are computed there, and every
+// pixel then gathers the adjoint of the replicate-padded Sobel from its 3x3 neighbourhood -- value and gradient of the
+// loss in ONE launch.  render is [H,W,D], depth = channel D-1.  partial[block] = (sum|a-b|, sum|Sa-Sb|) over the
+// block's owned pixels; v_render[...,D-1] is written for every pixel of rows [h0,h1).
+__global__ __launch_bounds__(256) void k_loss_fused(const float* __restrict__ render, int D,
+                                                    const float* __restrict__ gt, int W, int H, int r0, int r1, int h0,
+                                                    int h1, float depth_w, float edge_w, float inv_P,
+                                                    float* __restrict__ v_render, float* __restrict__ partial) {
+  __shared__ float sa[20][21], sg[20][21];  // masked depth images at (y0 - 2 + yy, x0 - 2 + xx), borders replicated
+  __shared__ float swx[18][19], swy[18][19];  // weights at (y0 - 1 + yy, x0 - 1 + xx); 0 outside the owned rows / image
   __shared__ float red[4][2];
-  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int tid = threadIdx.x;
+  int x0 = blockIdx.x * 16, y0 = h0 + blockIdx.y * 16;
+  for (int e = tid; e < 400; e += 256) {
+    int yy = e / 20, xx = e - yy * 20;
+    int y = clampi(y0 - 2 + yy, 0, H - 1), x = clampi(x0 - 2 + xx, 0, W - 1);
+    float d = render[((size_t)y * W + x) * D + (D - 1)];
+    sa[yy][xx] = d;                                          // d * m == d
+    sg[yy][xx] = d != 0.f ? gt[(size_t)y * W + x] : 0.f;    // g * m
+  }
+  __syncthreads();
+  float l1 = 0.f, le = 0.f;
+  for (int e = tid; e < 324; e += 256) {
+    int yy = e / 18, xx = e - yy * 18;
+    int y = y0 - 1 + yy, x = x0 - 1 + xx;
+    float wx = 0.f, wy = 0.f;
+    if (y >= r0 && y < r1 && x >= 0 && x < W) {
+      const int cy = yy + 1, cx = xx + 1;  // position in sa / sg
+      float gxa = ((sa[cy - 1][cx + 1] - sa[cy - 1][cx - 1]) + 2.f * (sa[cy][cx + 1] - sa[cy][cx - 1]) +
+                   (sa[cy + 1][cx + 1] - sa[cy + 1][cx - 1])) * 0.125f;
+      float gya = ((sa[cy + 1][cx - 1] - sa[cy - 1][cx - 1]) + 2.f * (sa[cy + 1][cx] - sa[cy - 1][cx]) +
+                   (sa[cy + 1][cx + 1] - sa[cy - 1][cx + 1])) * 0.125f;
+      float gxb = ((sg[cy - 1][cx + 1] - sg[cy - 1][cx - 1]) + 2.f * (sg[cy][cx + 1] - sg[cy][cx - 1]) +
+                   (sg[cy + 1][cx + 1] - sg[cy + 1][cx - 1])) * 0.125f;
+      float gyb = ((sg[cy + 1][cx - 1] - sg[cy - 1][cx - 1]) + 2.f * (sg[cy + 1][cx] - sg[cy - 1][cx]) +
+                   (sg[cy + 1][cx + 1] - sg[cy - 1][cx + 1])) * 0.125f;
+      float Sa = sqrtf(gxa * gxa + gya * gya + 1e-6f), Sb = sqrtf(gxb * gxb + gyb * gyb + 1e-6f);
+      float sgn = (Sa > Sb) ? 1.f : ((Sa < Sb) ? -1.f : 0.f);
+      wx = sgn * gxa / Sa;
+      wy = sgn * gya / Sa;
+      if (yy >= 1 && yy <= 16 && xx >= 1 && xx <= 16 && y < h1) {  // a pixel of this block: its loss terms
+        l1 += fabsf(sa[cy][cx] - sg[cy][cx]);
+        le += fabsf(Sa - Sb);
+      }
+    }
+    swx[yy][xx] = wx;
+    swy[yy][xx] = wy;
+  }
+  __syncthreads();
+  {
+    int ly = tid >> 4, lx = tid & 15;
+    int i = y0 + ly, j = x0 + lx;
+    if (i < h1 && j < W) {
+      size_t q = (size_t)i * W + j;
+      float d = sa[ly + 2][lx + 2];
+      float g = 0.f;
+      if (d != 0.f) {
+        // Sobel taps: Kx[a][b] = (b-1)*(a==1?2:1)/8, Ky[a][b] = (a-1)*(b==1?2:1)/8 at offset (a-1, b-1); tap (a,b)
+        // of pixel p reads clamp(p + (a-1, b-1)) and contributes to q when that equals q
+        float acc = 0.f;
+        for (int pi = max(i - 1, max(r0, 0)); pi <= min(i + 1, r1 - 1); ++pi)
+          for (int pj = max(j - 1, 0); pj <= min(j + 1, W - 1); ++pj) {
+            float wx = swx[pi - y0 + 1][pj - x0 + 1], wy = swy[pi - y0 + 1][pj - x0 + 1];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b)
+                if (clampi(pi + a - 1, 0, H - 1) == i && clampi(pj + b - 1, 0, W - 1) == j) {
+                  float kx = (float)(b - 1) * (a == 1 ? 2.f : 1.f) * 0.125f;
+                  float ky = (float)(a - 1) * (b == 1 ? 2.f : 1.f) * 0.125f;
+                  acc += wx * kx + wy * ky;
+                }
+          }
+        g = edge_w * acc;
+        if (i >= r0 && i < r1) {
+          float diff = d - sg[ly + 2][lx + 2];
+          g += depth_w * ((diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f));
+        }
+        g *= inv_P;
+      }
+      v_render[q * D + (D - 1)] = g;
+    }
+  }
+  int lane = tid & 63, wv = tid >> 6;
   float s1 = wave_sum(l1), s2 = wave_sum(le);
   if (lane == 0) { red[wv][0] = s1; red[wv][1] = s2; }
   __syncthreads();
-  if (threadIdx.x < 2)
-    partial[2 * (size_t)blockIdx.x + threadIdx.x] =
-        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
-// Stage 2: v_depth for every pixel of rows [h0,h1): the adjoint of the replicate-padded Sobel applied to
-// (wx, wy) of the owned rows, plus the L1 term on owned rows; written into v_render[...,D-1].
-__global__ __launch_bounds__(256) void k_loss_stage2(const float* __restrict__ render, int D,
-                                                     const float* __restrict__ gt, const float* __restrict__ wxy,
-                                                     int W, int H, int r0, int r1, int h0, int h1, float depth_w,
-                                                     float edge_w, float inv_P, float* __restrict__ v_render) {
-  int idx = blockIdx.x * 256 + threadIdx.x;
-  int n = (h1 - h0) * W;
-  if (idx >= n) return;
-  int i = h0 + idx / W, j = idx - (idx / W) * W;
-  size_t q = (size_t)i * W + j;
-  float d = render[q * D + (D - 1)];
-  float g = 0.f;
-  if (d != 0.f) {
-    // Sobel taps: Kx[a][b] = (b-1)*(a==1?2:1)/8, Ky[a][b] = (a-1)*(b==1?2:1)/8 at offset (a-1, b-1)
-    float acc = 0.f;
-    for (int pi = max(i - 1, r0); pi <= min(i + 1, r1 - 1); ++pi)
-      for (int pj = max(j - 1, 0); pj <= min(j + 1, W - 1); ++pj) {
-        float wx = wxy[2 * ((size_t)pi * W + pj)], wy = wxy[2 * ((size_t)pi * W + pj) + 1];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            // tap (a,b) of pixel p reads clamp(p + (a-1, b-1)); it contributes to q when that equals q
-            if (clampi(pi + a - 1, 0, H - 1) == i && clampi(pj + b - 1, 0, W - 1) == j) {
-              float kx = (float)(b - 1) * (a == 1 ? 2.f : 1.f) * 0.125f;
-              float ky = (float)(a - 1) * (b == 1 ? 2.f : 1.f) * 0.125f;
-              acc += wx * kx + wy * ky;
-            }
-          }
-      }
-    g = edge_w * acc;
-    if (i >= r0 && i < r1) {
-      float diff = d - gt[q];
-      g += depth_w * ((diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f));
-    }
-    g *= inv_P;
-  }
-  v_render[q * D + (D - 1)] = g;
+  if (tid < 2)
+    partial[2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,10 +343,14 @@ __global__ void k_pose_init(float* __restrict__ f, int* __restrict__ istate, con
   write_pose(q, t, c2w, viewmat);
 }
 
-// One optimisation step.  v_viewmat[16] = d loss / d viewmat (rows 0..2) summed over ranks already.
+// One optimisation step.  v_viewmat[16] = d loss / d viewmat (rows 0..2) summed over ranks already -- or, one rank,
+// vm_rows[n_vm][16]: the partial rows the projection backward left (gsl_fused_project_bwd, reduce_viewmat = 0), summed
+// here in a fixed order (saves the launch of the separate reduction); Kmat and the CURRENT viewmat are then read too.
 // partial[nb][2] loss sums of this rank (loss_sums_in != null: already reduced (sum_l1, sum_edge) over ranks).
 __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* __restrict__ istate,
                                                    const float* __restrict__ v_viewmat,
+                                                   const float* __restrict__ vm_rows, int n_vm,
+                                                   const float* __restrict__ Kmat,
                                                    const float* __restrict__ partial, int nb,
                                                    const float* __restrict__ loss_sums_in,
                                                    const float* __restrict__ normal_sum,
@@ -340,6 +359,15 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
                                                    float* __restrict__ loss_hist) {
   __shared__ float red[4][2];
   __shared__ float sums[2];
+  __shared__ float vred[4][15];
+  __shared__ float vtot[15];
+  __shared__ float svm[16];
+  if (vm_rows) {  // `viewmat` still holds the pose this iteration rendered with (thread 0 overwrites it at the very end)
+    float v = reduce_viewmat_rows(vm_rows, n_vm, viewmat, Kmat, vred, vtot);
+    if (threadIdx.x < 16) svm[threadIdx.x] = v;
+  } else if (threadIdx.x < 16) {
+    svm[threadIdx.x] = threadIdx.x < 12 ? v_viewmat[threadIdx.x] : 0.f;
+  }
   float a0 = 0.f, a1 = 0.f;
   if (loss_sums_in == nullptr) {
     for (int b = threadIdx.x; b < nb; b += 256) { a0 += partial[2 * (size_t)b]; a1 += partial[2 * (size_t)b + 1]; }
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
     V[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
   }
   V[12] = V[13] = V[14] = 0.f; V[15] = 1.f;
-  for (int k = 0; k < 12; ++k) vV[k] = v_viewmat[k];
+  for (int k = 0; k < 12; ++k) vV[k] = svm[k];
   vV[12] = vV[13] = vV[14] = vV[15] = 0.f;
   float M1[16];  // V^T vV
   for (int a = 0; a < 4; ++a)
@@ -454,17 +482,24 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
 // d loss / d viewmat), its two loss sums (fixed-order sum of its block partials) and, in entry 14, its sum of row
 // cosines of the normal-consistency term (0 when that term is off); entry 15 is zero.
 __global__ __launch_bounds__(256) void k_pack_pose_reduce(const float* __restrict__ v_viewmat,
+                                                          const float* __restrict__ vm_rows, int n_vm,
+                                                          const float* __restrict__ V, const float* __restrict__ Kmat,
                                                           const float* __restrict__ partial, int nb,
                                                           const float* __restrict__ normal_sum,
                                                           float* __restrict__ out16) {
   __shared__ float red[4][2];
+  __shared__ float vred[4][15];
+  __shared__ float vtot[15];
+  float vm = 0.f;
+  if (vm_rows) vm = reduce_viewmat_rows(vm_rows, n_vm, V, Kmat, vred, vtot);
+  else if (threadIdx.x < 12) vm = v_viewmat[threadIdx.x];
   float a0 = 0.f, a1 = 0.f;
   for (int b = threadIdx.x; b < nb; b += 256) { a0 += partial[2 * (size_t)b]; a1 += partial[2 * (size_t)b + 1]; }
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float s0 = wave_sum(a0), s1 = wave_sum(a1);
   if (lane == 0) { red[wv][0] = s0; red[wv][1] = s1; }
   __syncthreads();
-  if (threadIdx.x < 12) out16[threadIdx.x] = v_viewmat[threadIdx.x];
+  if (threadIdx.x < 12) out16[threadIdx.x] = vm;
   else if (threadIdx.x < 14)
     out16[threadIdx.x] = red[0][threadIdx.x - 12] + red[1][threadIdx.x - 12] + red[2][threadIdx.x - 12] + red[3][threadIdx.x - 12];
   else if (threadIdx.x == 14) out16[14] = normal_sum ? normal_sum[0] : 0.f;
@@ -473,19 +508,28 @@ __global__ __launch_bounds__(256) void k_pack_pose_reduce(const float* __restric
 
 }  // namespace gsl
 
-extern "C" int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials,
+extern "C" int gsl_pack_pose_reduce(const float* v_viewmat, const float* vm_rows, int n_vm_rows, const float* viewmat,
+                                    const float* K, const float* loss_partials, int n_partials,
                                     const float* normal_sum, float* out16, void* stream) {
-  if (!v_viewmat || !out16 || n_partials < 0 || (n_partials > 0 && !loss_partials)) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_pack_pose_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, v_viewmat, loss_partials,
-                     n_partials, normal_sum, out16);
+  if (!out16 || n_partials < 0 || (n_partials > 0 && !loss_partials)) return GSL_ERR_BAD_ARG;
+  if (!v_viewmat && !vm_rows) return GSL_ERR_BAD_ARG;
+  if (vm_rows && (n_vm_rows < 0 || !viewmat || !K)) return GSL_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gsl::k_pack_pose_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, v_viewmat, vm_rows,
+                     n_vm_rows, viewmat, K, loss_partials, n_partials, normal_sum, out16);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
 
+// number of (sum|a-b|, sum|Sa-Sb|) rows gsl_tracking_loss writes for the owned rows [row0,row1)
+extern "C" int gsl_loss_n_partials(int width, int height, int row0, int row1) {
+  if (width <= 0 || height <= 0 || row0 < 0 || row1 > height || row0 >= row1) return 0;
+  int h0 = row0 > 0 ? row0 - 1 : 0, h1 = row1 < height ? row1 + 1 : height;
+  return ((width + 15) / 16) * ((h1 - h0 + 15) / 16);
+}
+
 extern "C" size_t gsl_loss_ws_bytes(int width, int height) {
-  size_t P = (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0);
-  size_t nb = (P + 255) / 256;
-  return P * 2 * sizeof(float) + nb * 2 * sizeof(float);
+  int nb = gsl_loss_n_partials(width, height, 0, height);
+  return (size_t)(nb > 0 ? nb : 1) * 2 * sizeof(float);
 }
 
 extern "C" int gsl_tracking_loss(const float* render, int channels, const float* depth_gt, int width, int height,
@@ -493,23 +537,17 @@ extern "C" int gsl_tracking_loss(const float* render, int channels, const float*
                                  float* loss_partials, int* n_partials_host, void* ws, size_t ws_bytes,
                                  void* stream) {
   if (width <= 0 || height <= 0 || channels <= 0 || row0 < 0 || row1 > height || row0 > row1) return GSL_ERR_BAD_ARG;
-  if (!render || !depth_gt || !v_render || !ws) return GSL_ERR_BAD_ARG;
-  if (ws_bytes < gsl_loss_ws_bytes(width, height)) return GSL_ERR_WORKSPACE;
-  size_t P = (size_t)width * height;
-  float* wxy = (float*)ws;
-  float* partial = loss_partials ? loss_partials : (wxy + 2 * P);
-  int nown = (row1 - row0) * width;
-  int nb1 = (nown + 255) / 256;
-  if (n_partials_host) *n_partials_host = nb1;
-  if (nown == 0) return GSL_OK;
+  if (!render || !depth_gt || !v_render || (!ws && !loss_partials)) return GSL_ERR_BAD_ARG;
+  if (!loss_partials && ws_bytes < gsl_loss_ws_bytes(width, height)) return GSL_ERR_WORKSPACE;
+  float* partial = loss_partials ? loss_partials : (float*)ws;
+  int nb = gsl_loss_n_partials(width, height, row0, row1);
+  if (n_partials_host) *n_partials_host = nb;
+  if (nb == 0) return GSL_OK;
   int h0 = row0 > 0 ? row0 - 1 : 0, h1 = row1 < height ? row1 + 1 : height;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gsl::k_loss_stage1, dim3(nb1), dim3(256), 0, st, render, channels, depth_gt, width, height, row0,
-                     row1, wxy, partial);
-  GSL_CHECK_LAUNCH();
-  int n2 = (h1 - h0) * width;
-  hipLaunchKernelGGL(gsl::k_loss_stage2, dim3((n2 + 255) / 256), dim3(256), 0, st, render, channels, depth_gt, wxy,
-                     width, height, row0, row1, h0, h1, depth_lambda, edge_lambda, 1.0f / (float)P, v_render);
+  dim3 grid((width + 15) / 16, (h1 - h0 + 15) / 16);
+  hipLaunchKernelGGL(gsl::k_loss_fused, grid, dim3(256), 0, (hipStream_t)stream, render, channels, depth_gt, width,
+                     height, row0, row1, h0, h1, depth_lambda, edge_lambda, 1.0f / ((float)width * (float)height),
+                     v_render, partial);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -561,13 +599,15 @@ extern "C" int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, 
   return GSL_OK;
 }
 
-extern "C" int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* loss_partials,
-                             int n_partials, const float* loss_sums, const float* normal_sum, const float* gt_c2w,
+extern "C" int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* vm_rows, int n_vm_rows,
+                             const float* K, const float* loss_partials, int n_partials, const float* loss_sums, const float* normal_sum, const float* gt_c2w,
                              int width, int height, float depth_lambda, float edge_lambda, float normal_lambda,
                              float beta1, float beta2, float eps,
                              float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
                              int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream) {
-  if (!pose_f || !pose_i || !v_viewmat || !gt_c2w || !c2w || !viewmat) return GSL_ERR_BAD_ARG;
+  if (!pose_f || !pose_i || !gt_c2w || !c2w || !viewmat) return GSL_ERR_BAD_ARG;
+  if (!v_viewmat && !vm_rows) return GSL_ERR_BAD_ARG;
+  if (vm_rows && (n_vm_rows < 0 || !K)) return GSL_ERR_BAD_ARG;
   if (!loss_partials && !loss_sums) return GSL_ERR_BAD_ARG;
   if (width <= 0 || height <= 0 || n_partials < 0) return GSL_ERR_BAD_ARG;
   gsl::PoseHyper hp;
@@ -576,7 +616,7 @@ extern "C" int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat,
   hp.normal_w = normal_lambda; hp.inv_3H = 1.0f / (3.0f * (float)height);
   hp.min_step = min_step; hp.patience = patience; hp.early_stop = early_stop; hp.max_steps = max_steps;
   hipLaunchKernelGGL(gsl::k_pose_step, dim3(1), dim3(256), 0, (hipStream_t)stream, pose_f, pose_i, v_viewmat,
-                     loss_partials, n_partials, loss_sums, normal_sum, gt_c2w, hp, c2w, viewmat, loss_hist);
+                     vm_rows, n_vm_rows, K, loss_partials, n_partials, loss_sums, normal_sum, gt_c2w, hp, c2w, viewmat, loss_hist);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

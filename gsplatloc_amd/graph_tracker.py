@@ -76,7 +76,7 @@ class GraphTracker:
         self.v_alphas = torch.zeros(self.H, self.W, 1, dtype=f32, device=d)
         self.loss_ws_bytes = self.lib.gsl_loss_ws_bytes(self.W, self.H)
         self.loss_ws = torch.zeros(self.loss_ws_bytes, dtype=torch.uint8, device=d)
-        self.n_partials = ((self.row1 - self.row0) * self.W + 255) // 256
+        self.n_partials = self.lib.gsl_loss_n_partials(self.W, self.H, self.row0, self.row1)
         self.partials = torch.zeros(max(self.n_partials, 1) * 2, dtype=f32, device=d)
         self.loss_hist = torch.zeros(max(config.max_steps, 1), dtype=f32, device=d)
         self.reduce_buf = torch.zeros(16, dtype=f32, device=d)  # 12 pose-gradient entries + 2 loss sums + row cosines
@@ -134,22 +134,27 @@ class GraphTracker:
                                       self.row1, *self._intrinsics, cfg.normal_lambda, ptr(self.v_render),
                                       ptr(self.normal_sum), ptr(self.normal_ws), self.normal_ws_bytes, st),
                   "gsl_normal_loss")
-        self.rc.backward(self.v_render, self.v_alphas, full=False)
+        # the pose gradient stays as partial rows: the pack kernel / the pose step sum them (one launch fewer)
+        self.rc.backward(self.v_render, self.v_alphas, full=False, reduce_viewmat=False)
         if self.group is not None:
-            check(lib.gsl_pack_pose_reduce(ptr(self.rc.v_viewmat), ptr(self.partials), self.n_partials,
-                                           ptr(self.normal_sum), ptr(self.reduce_buf), st), "gsl_pack_pose_reduce")
+            rows, n_rows = self.rc.viewmat_rows()
+            check(lib.gsl_pack_pose_reduce(None, rows, n_rows, ptr(self.viewmat), ptr(self.K), ptr(self.partials),
+                                           self.n_partials, ptr(self.normal_sum), ptr(self.reduce_buf), st),
+                  "gsl_pack_pose_reduce")
 
     def _pose_step(self) -> None:
         cfg, lib = self.cfg, self.lib
         if self.group is not None:  # summed over the ranks: gradient in [0,12), loss sums in [12,14)
             v_viewmat, loss_sums = ptr(self.reduce_buf), self.reduce_buf.data_ptr() + 12 * 4
+            rows, n_rows = None, 0
         else:
-            v_viewmat, loss_sums = ptr(self.rc.v_viewmat), None
+            v_viewmat, loss_sums = None, None
+            rows, n_rows = self.rc.viewmat_rows()
         cam = cfg.camera
         edge_w = 1.0 - cfg.depth_lambda - cfg.normal_lambda
         gamma = 0.2 ** (1.0 / cfg.max_steps)
-        check(lib.gsl_pose_step(ptr(self.pose_f), ptr(self.pose_i), v_viewmat, ptr(self.partials),
-                                self.n_partials, loss_sums, ptr(self.normal_sum), ptr(self.gt_c2w), self.W, self.H,
+        check(lib.gsl_pose_step(ptr(self.pose_f), ptr(self.pose_i), v_viewmat, rows, n_rows, ptr(self.K),
+                                ptr(self.partials), self.n_partials, loss_sums, ptr(self.normal_sum), ptr(self.gt_c2w), self.W, self.H,
                                 cfg.depth_lambda, edge_w, cfg.normal_lambda, 0.9, 0.999, 1e-8, cam.quat_opt_reg,
                                 cam.trans_opt_reg, gamma, cfg.min_step,
                                 cfg.patience, int(cfg.early_stop), cfg.max_steps, ptr(self.c2w), ptr(self.viewmat),

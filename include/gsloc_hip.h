@@ -181,7 +181,10 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     (flags: 4 ints, may be NULL): poll it and re-run with larger bins.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
- *                     v_viewmat[16] is overwritten (row 3 = 0). */
+ *                     v_viewmat[16] is overwritten (row 3 = 0).  reduce_viewmat = 0 skips that last reduction
+ *                     launch and leaves the pose gradient as ceil(N/256) partial rows of 16 floats at
+ *                     gsl_fused_viewmat_rows(ws, n_tiles) for gsl_pose_step / gsl_pack_pose_reduce to sum
+ *                     (same fixed order, same result; v_viewmat may then be NULL). */
 size_t gsl_fused_ws_bytes(int N, int n_tiles);
 int gsl_fused_project(const float* means, const float* quats, const float* scales,
                       const float* opacities, const float* colors, int sh_degree, int K_sh,
@@ -214,7 +217,8 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
                           const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0, int tile_w,
-                          int tile_h, int ty0, int ty1, int64_t capacity, void* stream);
+                          int tile_h, int ty0, int ty1, int64_t capacity, int reduce_viewmat, void* stream);
+const float* gsl_fused_viewmat_rows(const void* ws, int n_tiles);
 
 /* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4
  * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_fused_raster_bwd: instead of
@@ -240,13 +244,16 @@ int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int 
  * gsl_tracking_loss: depth L1 + Sobel-edge L1 of render[...,channels-1] against depth_gt[H,W] over the owned
  *   pixel rows [row0,row1) (whole image: 0,height), normalised by width*height; writes d loss / d depth into
  *   v_render[...,channels-1] for rows [row0-1,row1+1) and the block sums (sum|a-b|, sum|Sa-Sb|) into
- *   loss_partials[ceil((row1-row0)*width/256)][2] (inside ws when NULL).  ws: gsl_loss_ws_bytes.
+ *   loss_partials[gsl_loss_n_partials(width,height,row0,row1)][2] (inside ws when NULL; ws may be NULL otherwise).
+ *   One launch: 16x16 pixel blocks with a two-pixel apron through LDS.  ws: gsl_loss_ws_bytes.
  * gsl_pose_init : pose state <- init_c2w (wxyz quaternion + translation), zero Adam moments, step 0; writes
  *   c2w[16] and viewmat[16] = c2w^-1.  pose_f[32] floats, pose_i[4] ints (layout: csrc/tracker.hip).
  * gsl_pose_step : finish the loss, pose errors vs gt_c2w, early-stop bookkeeping (best loss after min_step,
  *   patience), pose chain viewmat->(quat,t), two Adam updates (weight decay in the gradient), lr *= gamma,
  *   new c2w / viewmat; appends the loss to loss_hist[max_steps] (may be NULL).  Does nothing once stopped
- *   (pose_i[2]).  loss_sums[3] (already summed over ranks: the two sums and the row-cosine sum) overrides
+ *   (pose_i[2]).  The pose gradient is v_viewmat[16], or -- vm_rows not NULL -- the n_vm_rows partial rows a
+ *   gsl_fused_project_bwd(reduce_viewmat = 0) left (K and the viewmat buffer, which still holds the rendered pose, are
+ *   read for the camera-position chain).  loss_sums[3] (already summed over ranks: the two sums and the row-cosine sum) overrides
  *   loss_partials / normal_sum when not NULL.  normal_lambda != 0 adds normal_lambda * (1 - normal_sum / (3 height)).
  * gsl_normal_loss: the normal-consistency term the reference defines and keeps switched off (loss.py:62-101 "cosine",
  *   geometry.py:164-197; call commented out at gs_trainer_total.py:138-143, normal_lambda = 0 at data/base.py:28):
@@ -256,6 +263,7 @@ int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int 
  *   gsl_tracking_loss, which writes that channel) and writes the sum of the owned rows' cosines to normal_sum[0].
  *   ws: gsl_normal_ws_bytes. */
 size_t gsl_loss_ws_bytes(int width, int height);
+int gsl_loss_n_partials(int width, int height, int row0, int row1);
 size_t gsl_normal_ws_bytes(int width, int height);
 int gsl_normal_loss(const float* render, int channels, const float* depth_gt, int width, int height, int row0,
                     int row1, float fx, float fy, float cx, float cy, float normal_lambda, float* v_render,
@@ -265,19 +273,20 @@ int gsl_tracking_loss(const float* render, int channels, const float* depth_gt, 
                       float* loss_partials, int* n_partials_host, void* ws, size_t ws_bytes, void* stream);
 int gsl_pose_init(float* pose_f, int* pose_i, const float* init_c2w, float lr_quat, float lr_trans,
                   float* c2w, float* viewmat, void* stream);
-int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* loss_partials,
-                  int n_partials, const float* loss_sums, const float* normal_sum, const float* gt_c2w,
+int gsl_pose_step(float* pose_f, int* pose_i, const float* v_viewmat, const float* vm_rows, int n_vm_rows,
+                  const float* K, const float* loss_partials, int n_partials, const float* loss_sums, const float* normal_sum, const float* gt_c2w,
                   int width, int height, float depth_lambda, float edge_lambda, float normal_lambda,
                   float beta1, float beta2, float eps,
                   float wd_quat, float wd_trans, float gamma, int min_step, int patience, int early_stop,
                   int max_steps, float* c2w, float* viewmat, float* loss_hist, void* stream);
 /* Several GPUs: what one rank contributes to the ONE all-reduce of an iteration.  out16[0..11] =
- * v_viewmat[0..11] of its strip, out16[12..13] = its (sum |d - g|, sum |S(d) - S(g)|) over loss_partials[n][2]
+ * v_viewmat[0..11] of its strip (given reduced, or as vm_rows with the viewmat and K they were computed at), out16[12..13] = its (sum |d - g|, sum |S(d) - S(g)|) over loss_partials[n][2]
  * (fixed order), out16[14] = normal_sum[0] (0 when NULL), out16[15] = 0.  After the all-reduce (sum) gsl_pose_step
  * takes v_viewmat = out16 and loss_sums = out16 + 12.  Written by a kernel of this library so that a captured
  * iteration holds no foreign node. */
-int gsl_pack_pose_reduce(const float* v_viewmat, const float* loss_partials, int n_partials,
-                         const float* normal_sum, float* out16, void* stream);
+int gsl_pack_pose_reduce(const float* v_viewmat, const float* vm_rows, int n_vm_rows, const float* viewmat,
+                         const float* K, const float* loss_partials, int n_partials, const float* normal_sum,
+                         float* out16, void* stream);
 
 /* ---- per-frame set-up: exact k nearest neighbours on the device (csrc/knn.hip) ----
  * Stands in for the small_gicp KdTree search of /root/reference/src/my_gsplat/utils.py:16-22.

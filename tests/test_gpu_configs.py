@@ -240,7 +240,7 @@ def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
     ws_bytes = lib.gsl_loss_ws_bytes(W, H)
     ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
     v_render = torch.zeros(H, W, 4, device=dev)
-    partials = torch.zeros(((H * W + 255) // 256) * 2, device=dev)
+    partials = torch.zeros(lib.gsl_loss_n_partials(W, H, 0, H) * 2, device=dev)
     check(lib.gsl_tracking_loss(ptr(ctx.render), 4, ptr(gt), W, H, 0, H, 0.8, 0.2, ptr(v_render), ptr(partials), None,
                                 ptr(ws), ws_bytes, current_stream()), "gsl_tracking_loss")
     got = ctx.backward(v_render, torch.zeros(H, W, 1, device=dev), full=False)["viewmat"].cpu().double()

@@ -107,7 +107,7 @@ def test_fused_loss_kernel_matches_autograd_loss():
             row0, row1 = rows[0] * 16, min(rows[1] * 16, H)
         total.backward()
         v = torch.zeros(H, W, D, device=DEV)
-        nb = ((row1 - row0) * W + 255) // 256
+        nb = lib.gsl_loss_n_partials(W, H, row0, row1)
         partials = torch.zeros(nb * 2, device=DEV)
         check(lib.gsl_tracking_loss(ptr(render), D, ptr(gt), W, H, row0, row1, 0.8, 0.2, ptr(v), ptr(partials), None,
                                     ptr(ws), ws_bytes, None), "loss")
@@ -156,7 +156,7 @@ def test_fused_normal_loss_kernel_matches_autograd_loss():
             row0, row1 = rows[0] * 16, min(rows[1] * 16, H)
         total.backward()
         v = torch.zeros(H, W, D, device=DEV)
-        nb = ((row1 - row0) * W + 255) // 256
+        nb = lib.gsl_loss_n_partials(W, H, row0, row1)
         partials = torch.zeros(nb * 2, device=DEV)
         nsum = torch.full((1,), -7.0, device=DEV)
         check(lib.gsl_tracking_loss(ptr(r32), D, ptr(gt32), W, H, row0, row1, lam_d, 1 - lam_d - lam_n, ptr(v),

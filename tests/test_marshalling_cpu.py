@@ -57,7 +57,8 @@ def test_tracker_kernel_calls_marshal():
     render, gt, v_render = torch.zeros(H, W, D), torch.ones(H, W), torch.zeros(H, W, D)
     ws_bytes = lib.gsl_loss_ws_bytes(W, H)
     ws = torch.zeros(ws_bytes, dtype=torch.uint8)
-    n_part = (H * W + 255) // 256
+    n_part = lib.gsl_loss_n_partials(W, H, 0, H)
+    assert n_part == 4 * 3 and lib.gsl_loss_n_partials(W, H, 16, 32) == 4 * 2 and lib.gsl_loss_n_partials(W, H, 5, 5) == 0
     partials = torch.zeros(n_part * 2)
     pose_f, pose_i = torch.zeros(32), torch.zeros(4, dtype=torch.int32)
     c2w, viewmat, eye = torch.eye(4), torch.eye(4), torch.eye(4)
@@ -76,7 +77,7 @@ def test_tracker_kernel_calls_marshal():
                                ptr(nws), nws_bytes, None) == -1  # fx = 0: bad argument, checked before any launch
     assert lib.gsl_normal_loss(ptr(render), D, ptr(gt), W, H, 0, H, 300.0, 300.0, 31.5, 23.5, 0.1, ptr(v_render), ptr(nsum),
                                ptr(nws), nws_bytes - 4, None) < 0  # workspace too small
-    _expect_hip_refusal(lambda: check(lib.gsl_pose_step(ptr(pose_f), ptr(pose_i), ptr(v_viewmat), ptr(partials), n_part,
+    _expect_hip_refusal(lambda: check(lib.gsl_pose_step(ptr(pose_f), ptr(pose_i), ptr(v_viewmat), None, 0, None, ptr(partials), n_part,
                                                         None, ptr(nsum), ptr(eye), W, H, 0.7, 0.2, 0.1, 0.9, 0.999, 1e-8,
                                                         1e-3, 1e-3, 0.99, 100, 200, 1, 10, ptr(c2w), ptr(viewmat),
                                                         ptr(hist), None),
