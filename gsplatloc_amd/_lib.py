@@ -62,8 +62,7 @@ _SIGNATURES = {
     "gsl_knn_query": (c_int, [P, c_int, P, P, c_int, P, P, c_size_t, P]),
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P, P, P, P, c_int, c_int,
-                                      c_int, c_int, c_int64, c_int, P]),
-    "gsl_tiny_gather": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P, P, P]),
+                                      c_int, c_int, c_int64, P, P, c_int, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                     P, P, P, P, P, P, P, c_int, c_int, P, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),

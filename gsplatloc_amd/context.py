@@ -209,9 +209,7 @@ class RenderContext:
         if self.tiny:
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), self.row0, self.row1,
                                                ptr(self.flags), current_stream()), "gsl_tiny_raster_bwd")
-            check(self.lib.gsl_tiny_gather(ptr(self.Q0), ptr(self.Q1), ptr(self.radii), self.N, self.D, self.W, self.H,
-                                           ptr(self.trec), ptr(self.vcT), ptr(self.vacc), current_stream()),
-                  "gsl_tiny_gather")
+            # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
                                                 ptr(self.vrow), current_stream()), "gsl_fused_raster_bwd")
@@ -223,6 +221,9 @@ class RenderContext:
                    self.capacity)
         else:  # (the tiny-splat backward has no atomics to begin with)
             det = (None, None, None, None, 0, 0, 0, 0, 0)
+        tiny = (ptr(self.trec), ptr(self.vcT)) if self.tiny else (None, None)
+        if tiny[0] is not None:  # the projection backward folds the slabs itself: it needs the records
+            det = (None, None, None, ptr(self.Q0), 0, 0, 0, 0, 0)
         check(self.lib.gsl_fused_project_bwd(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
@@ -230,7 +231,7 @@ class RenderContext:
             ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
             ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
             ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
-            self.n_tiles, *det, int(reduce), current_stream()), "gsl_fused_project_bwd")
+            self.n_tiles, *det, *tiny, int(reduce), current_stream()), "gsl_fused_project_bwd")
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],

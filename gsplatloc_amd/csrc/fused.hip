@@ -663,10 +663,30 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
     float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
     float* __restrict__ partials, const float4* __restrict__ vrow, const uint64_t* __restrict__ skeys,
     const int32_t* __restrict__ tile_offsets, const float4* __restrict__ Q0, int tile_w, int tile_h, int ty0, int ty1,
-    long long capacity) {
+    long long capacity, float4* __restrict__ trec, const float* __restrict__ vcT) {
   constexpr bool RGB = D >= 3;
   int i = blockIdx.x * 256 + threadIdx.x;
   Cam cam = load_cam(V, Kmat);
+  // tiny-splat backward, pass 2 fused in: four lanes per Gaussian fold its 4x4 slab of (w, alpha*T) records into the
+  // gradient row, which stays in LDS for the thread that owns the Gaussian (no row round trip, no gather launch)
+  __shared__ float4 srow[256][3];
+  if (trec) {
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      int t = pass * 256 + threadIdx.x;
+      int lg = t >> 2, r = t & 3, gid = blockIdx.x * 256 + lg;
+      bool lv = gid < N && radii[gid] > 0;
+      float v[6 + D];
+      tiny_fold_slab<D>(Q0, Q1, W, H, trec, vcT, gid, r, lv, v);
+      float pad[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) pad[k] = (k < 6 + D) ? v[k] : 0.f;
+      if (r == 0) srow[lg][0] = make_float4(pad[0], pad[1], pad[2], pad[3]);
+      if (r == 1) srow[lg][1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
+      if (r == 2) srow[lg][2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
+    }
+    __syncthreads();
+  }
   float acc15[15];
 #pragma unroll
   for (int k = 0; k < 15; ++k) acc15[k] = 0.f;
@@ -703,6 +723,8 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
             r2.x += c.x; r2.y += c.y; r2.z += c.z; r2.w += c.w;
           }
         }
+    } else if (trec) {
+      r0 = srow[threadIdx.x][0]; r1 = srow[threadIdx.x][1]; r2 = srow[threadIdx.x][2];
     } else {
       r0 = vacc[4 * (size_t)i]; r1 = vacc[4 * (size_t)i + 1]; r2 = vacc[4 * (size_t)i + 2];
       vacc[4 * (size_t)i] = z; vacc[4 * (size_t)i + 1] = z; vacc[4 * (size_t)i + 2] = z;
@@ -956,8 +978,8 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
                                      float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                                      float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
                                      const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0,
-                                     int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
-                                     int reduce_viewmat, void* stream) {
+                                     int tile_w, int tile_h, int ty0, int ty1, int64_t capacity, float* tiny_trec,
+                                     const float* tiny_vcT, int reduce_viewmat, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || n_tiles <= 0) return GSL_ERR_BAD_ARG;
   if (reduce_viewmat && !v_viewmat) return GSL_ERR_BAD_ARG;
   if (channels != 1 && channels != 3 && channels != 4) return GSL_ERR_BAD_ARG;
@@ -972,7 +994,8 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     return GSL_OK;
   }
   if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !Q1) return GSL_ERR_BAD_ARG;
-  if (!vrow && !vacc) return GSL_ERR_BAD_ARG;
+  if (!vrow && !vacc && !tiny_trec) return GSL_ERR_BAD_ARG;
+  if (tiny_trec && (!tiny_vcT || !Q0 || vrow)) return GSL_ERR_BAD_ARG;
   if (vrow && (!sorted_keys || !tile_offsets || !Q0 || tile_w <= 0 || tile_h <= 0 || tile_w * tile_h != n_tiles ||
                ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0))
     return GSL_ERR_BAD_ARG;
@@ -986,7 +1009,7 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
                      colors, sh_degree, K_sh, viewmat, K, N, width, height, eps2d, antialiased, radii,             \
                      (const float4*)Q1, compensations, (float4*)vacc, v_means, v_quats, v_scales, v_opacities,    \
                      v_colors, partials, (const float4*)vrow, sorted_keys, tile_offsets, (const float4*)Q0, tile_w,   \
-                     tile_h, ty0, ty1, (long long)capacity)
+                     tile_h, ty0, ty1, (long long)capacity, (float4*)tiny_trec, tiny_vcT)
   if (full) {
     if (channels == 1) CALL_PB(true, 1); else if (channels == 3) CALL_PB(true, 3); else CALL_PB(true, 4);
   } else {

@@ -213,6 +213,64 @@ __device__ __forceinline__ float reduce_viewmat_rows(const float* __restrict__ p
   return v;
 }
 
+// ---- tiny-splat backward, pass 2 (csrc/raster_px.hip has pass 1 and the story) ---------------------------------------
+__device__ __forceinline__ int tiny_origin(float centre, float r) {  // first pixel index within r of centre
+  return (int)ceilf(centre - r - 0.5f);
+}
+
+// Lane r (0..3) of a quad folds row r of Gaussian gid's 4x4 slab of (w, alpha*T) records into the gradient row
+// [v_xy 2 | v_conic 3 | v_opacity 1 | v_colour D] (dx, dy rebuilt from the Gaussian's own record), clears the slab row,
+// and the quad's four partial rows are added up: every lane of the quad returns the Gaussian's total.
+template <int D>
+__device__ __forceinline__ void tiny_fold_slab(const float4* __restrict__ Q0, const float4* __restrict__ Q1, int W,
+                                               int H, float4* __restrict__ trec, const float* __restrict__ vcT,
+                                               int gid, int r, bool live, float (&v)[6 + D]) {
+  constexpr int A = 6 + D;
+#pragma unroll
+  for (int k = 0; k < A; ++k) v[k] = 0.f;
+  if (live) {
+    float4* row = trec + (size_t)gid * 8 + 2 * r;  // slab = 16 float2 = 8 float4; row r = float4 2r, 2r+1
+    float4 lo = row[0], hi = row[1];
+    float w[4] = {lo.x, lo.z, hi.x, hi.z}, f[4] = {lo.y, lo.w, hi.y, hi.w};
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) any = any || (w[c] != 0.f) || (f[c] != 0.f);
+    if (any) {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      row[0] = z;
+      row[1] = z;
+      float4 q0 = Q0[gid], qc = Q1[gid];
+      int pcol0 = tiny_origin(q0.x, qc.w), prow = tiny_origin(q0.y, qc.w) + r;
+      float dy = q0.y - ((float)prow + 0.5f);
+      bool row_in = (unsigned)prow < (unsigned)H;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (w[c] != 0.f || f[c] != 0.f) {
+          int pcol = pcol0 + c;
+          float dx = q0.x - ((float)pcol + 0.5f);
+          float gx = qc.x * dx + qc.y * dy, gy = qc.y * dx + qc.z * dy;
+          float v_sigma = -q0.w * w[c], hs = 0.5f * v_sigma;
+          v[0] += v_sigma * gx; v[1] += v_sigma * gy;
+          v[2] += hs * dx * dx; v[3] += v_sigma * dx * dy; v[4] += hs * dy * dy;
+          v[5] += w[c];
+          if (f[c] != 0.f && row_in && (unsigned)pcol < (unsigned)W) {
+            size_t pid = (size_t)prow * W + pcol;
+#pragma unroll
+            for (int k = 0; k < D; ++k) v[6 + k] += f[c] * vcT[pid * D + k];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < A; ++k) {
+    float x = v[k];
+    x += dpp_get<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp_get<0x4E>(x);  // quad_perm [2,3,0,1]: every lane of the quad holds the Gaussian's total
+    v[k] = x;
+  }
+}
+
 // Tile rectangle of a projected Gaussian: [xmin,xmax) x [ymin,ymax) in tiles.
 __device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tile_size, int tile_w,
                                           int tile_h, int& xmin, int& ymin, int& xmax, int& ymax) {

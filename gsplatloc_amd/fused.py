@@ -131,7 +131,7 @@ class _FusedRasterization(torch.autograd.Function):
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rgb else None, sh_degree, ctx.K_sh,
             ptr(viewmat), ptr(K), N, W, H, eps2d, int(antialiased), D, ptr(radii), ptr(Q1),
             ptr(comps) if antialiased else None, ptr(vacc), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opac),
-            ptr(v_colors), ptr(v_viewmat), ptr(ws), ws_bytes, n_tiles, None, None, None, None, 0, 0, 0, 0, 0, 1, st),
+            ptr(v_colors), ptr(v_viewmat), ptr(ws), ws_bytes, n_tiles, None, None, None, None, 0, 0, 0, 0, 0, None, None, 1, st),
             "gsl_fused_project_bwd")
         return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
                 v_opac if ni[3] else None, v_colors if (ni[4] and rgb) else None, v_viewmat, None, None, None)

@@ -181,7 +181,10 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     (flags: 4 ints, may be NULL): poll it and re-run with larger bins.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
- *                     v_viewmat[16] is overwritten (row 3 = 0).  reduce_viewmat = 0 skips that last reduction
+ *                     v_viewmat[16] is overwritten (row 3 = 0).  tiny_trec / tiny_vcT (may be NULL): the slabs
+ *                     gsl_tiny_raster_bwd filled; the kernel then folds them itself (pass 2 of the tiny-splat
+ *                     backward fused in: the gradient rows never leave LDS, vacc is not touched, Q0 required)
+ *                     instead of reading vacc.  reduce_viewmat = 0 skips that last reduction
  *                     launch and leaves the pose gradient as ceil(N/256) partial rows of 16 floats at
  *                     gsl_fused_viewmat_rows(ws, n_tiles) for gsl_pose_step / gsl_pack_pose_reduce to sum
  *                     (same fixed order, same result; v_viewmat may then be NULL). */
@@ -217,15 +220,16 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_quats, float* v_scales, float* v_opacities, float* v_colors,
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
                           const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0, int tile_w,
-                          int tile_h, int ty0, int ty1, int64_t capacity, int reduce_viewmat, void* stream);
+                          int tile_h, int ty0, int ty1, int64_t capacity, float* tiny_trec, const float* tiny_vcT,
+                          int reduce_viewmat, void* stream);
 const float* gsl_fused_viewmat_rows(const void* ws, int n_tiles);
 
 /* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4
  * pixel centres (GsplatLoc's as-coded scales).  gsl_tiny_raster_bwd replaces gsl_fused_raster_bwd: instead of
  * reducing and accumulating gradient rows it stores per (splat, pixel) records into trec[N][16][2] (zero on
- * entry) and the chained upstream gradient of every pixel into vcT[H,W,channels]; gsl_tiny_gather then sums
- * each Gaussian's 4x4 slab into its vacc row (overwritten, same layout as above) and clears the slab.
- * gsl_fused_project_bwd follows unchanged.  flags (int32[1], may be NULL): flags[0] is set to 1 when a
+ * entry) and the chained upstream gradient of every pixel into vcT[H,W,channels]; gsl_fused_project_bwd given
+ * tiny_trec / tiny_vcT then sums each Gaussian's 4x4 slab into its gradient row (in LDS, four lanes per Gaussian)
+ * and clears the slab.  flags (int32[1], may be NULL): flags[0] is set to 1 when a
  * (pixel, splat) pair fell outside its slab, i.e. the precondition did not hold and the gradients are
  * incomplete -- the caller polls it and re-runs the iteration with gsl_fused_raster_bwd. */
 int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
@@ -234,8 +238,6 @@ int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int c
                         const float* render, const float* alphas, const int32_t* last_ids,
                         const float* v_render, const float* v_alphas, float* trec, float* vcT,
                         int row0, int row1, int32_t* flags, void* stream);
-int gsl_tiny_gather(const float* Q0, const float* Q1, const int32_t* radii, int N, int channels, int width,
-                    int height, float* trec, const float* vcT, float* vacc, void* stream);
 
 /* ---- tracker tail: loss + pose update on device (csrc/tracker.hip) ----
  * Replaces the PyTorch/kornia glue of one iteration of GsplatLoc's Runner.train

@@ -40,11 +40,6 @@ def test_render_context_stage_calls_marshal(mode, full, tiny, pixel_rows, monkey
     _expect_hip_refusal(ctx._bin, "bin")
     _expect_hip_refusal(ctx._raster_fwd, "raster fwd")
     _expect_hip_refusal(lambda: ctx._raster_bwd(v, va), "raster bwd")
-    if tiny:  # the first call of the pair already refused: exercise the gather on its own as well
-        from gsplatloc_amd._lib import check, ptr
-        _expect_hip_refusal(lambda: check(ctx.lib.gsl_tiny_gather(ptr(ctx.Q0), ptr(ctx.Q1), ptr(ctx.radii), ctx.N, ctx.D,
-                                                                  ctx.W, ctx.H, ptr(ctx.trec), ptr(ctx.vcT), ptr(ctx.vacc),
-                                                                  None), "gsl_tiny_gather"), "gather")
     with pytest.raises(RuntimeError, match=r"gsl_fused_project_bwd failed: HIP launch error \(status -3\)"):
         ctx._project_bwd(full)
 
@@ -124,7 +119,7 @@ def test_graph_tracker_iteration_marshals_every_call(monkeypatch):
     # nothing was projected (the launch was refused), so every r_cull is 0 and calibration picked the tiny backward
     assert gt.rc.tiny
     assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_bin", "gsl_fused_raster_fwd", "gsl_tracking_loss",
-                               "gsl_tiny_raster_bwd", "gsl_tiny_gather", "gsl_fused_project_bwd", "gsl_pose_step"]
+                               "gsl_tiny_raster_bwd", "gsl_fused_project_bwd", "gsl_pose_step"]
 
 
 @pytest.mark.parametrize("mode,sh_degree", [("RGB+ED", 1), ("ED", None), ("RGB", None)])
