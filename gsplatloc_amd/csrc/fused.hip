@@ -837,16 +837,19 @@ __global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict
 }  // namespace gsl
 
 // ---------------------------------------------------------------------------------------------- C ABI
+// ws = [tile_counts n_tiles][cursors n_tiles][pad to 16 bytes][pose-gradient rows ceil(N/256) x 16 floats]
+static inline size_t gsl_vm_rows_offset(int n_tiles) { return ((size_t)2 * (size_t)n_tiles * sizeof(int32_t) + 15) & ~(size_t)15; }
+
 extern "C" size_t gsl_fused_ws_bytes(int N, int n_tiles) {
   // [tile_counts n_tiles][cursors n_tiles][partials ceil(N/256)*16 floats]
   size_t nb = ((size_t)(N > 0 ? N : 1) + 255) / 256;
-  return (size_t)2 * (size_t)(n_tiles > 0 ? n_tiles : 1) * sizeof(int32_t) + nb * 16 * sizeof(float);
+  return gsl_vm_rows_offset(n_tiles > 0 ? n_tiles : 1) + nb * 16 * sizeof(float);
 }
 
 // where gsl_fused_project_bwd leaves the pose-gradient rows inside ws: ceil(N / 256) rows of 16 floats (15 used)
 extern "C" const float* gsl_fused_viewmat_rows(const void* ws, int n_tiles) {
   if (!ws || n_tiles <= 0) return nullptr;
-  return (const float*)((const int32_t*)ws + 2 * (size_t)n_tiles);
+  return (const float*)((const char*)ws + gsl_vm_rows_offset(n_tiles));
 }
 
 extern "C" int gsl_fused_project(const float* means, const float* quats, const float* scales, const float* opacities,
@@ -1002,7 +1005,7 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
   if (channels >= 3 && !colors) return GSL_ERR_BAD_ARG;
   if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
   // one row of 15 sums per workgroup; reduce_viewmat = 0 leaves them for gsl_pose_step / gsl_pack_pose_reduce
-  float* partials = (float*)((int32_t*)ws + 2 * (size_t)n_tiles);
+  float* partials = (float*)((char*)ws + gsl_vm_rows_offset(n_tiles));
   int grid = (N + 255) / 256;
 #define CALL_PB(FF, DD)                                                                                          \
   hipLaunchKernelGGL((gsl::k_fproject_bwd<FF, DD>), dim3(grid), dim3(256), 0, st, means, quats, scales, opacities, \

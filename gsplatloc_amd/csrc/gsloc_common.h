@@ -181,17 +181,33 @@ __device__ __forceinline__ void cam_inverse(const Cam& cam, M3& Ri, float cp[3])
 __device__ __forceinline__ float reduce_viewmat_rows(const float* __restrict__ partials, int nb,
                                                      const float* __restrict__ V, const float* __restrict__ Kmat,
                                                      float (*red)[15], float* tot) {
-  float acc[15];
-#pragma unroll
-  for (int k = 0; k < 15; ++k) acc[k] = 0.f;
-  for (int b = threadIdx.x; b < nb; b += 256)
-#pragma unroll
-    for (int k = 0; k < 15; ++k) acc[k] += partials[(size_t)b * 16 + k];
+  // thread (row r0 = tid >> 2, quarter q = tid & 3) adds quarter q of rows r0, r0 + 64, ...: 16-byte coalesced loads,
+  // four rows in flight; then lanes of equal q are folded (xor 4 .. 32) and the four waves summed in wave order
+  int q = threadIdx.x & 3;
+  const float4* rows = reinterpret_cast<const float4*>(partials) + q;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  int b = threadIdx.x >> 2;
+  for (; b + 192 < nb; b += 256) {
+    float4 x0 = rows[(size_t)b * 4], x1 = rows[(size_t)(b + 64) * 4], x2 = rows[(size_t)(b + 128) * 4],
+           x3 = rows[(size_t)(b + 192) * 4];
+    a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+    a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+    a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+    a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
+  }
+  for (; b < nb; b += 64) {
+    float4 x0 = rows[(size_t)b * 4];
+    a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+  }
+  float v4[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                 (a0.w + a1.w) + (a2.w + a3.w)};
   int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int k = 0; k < 15; ++k) {
-    float s = wave_sum(acc[k]);
-    if (lane == 0) red[wv][k] = s;
+  for (int c = 0; c < 4; ++c) {
+    float x = v4[c];
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+    if (lane < 4 && 4 * q + c < 15) red[wv][4 * q + c] = x;
   }
   __syncthreads();
   if (threadIdx.x < 15) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
