@@ -461,6 +461,60 @@ def test_binned_projection_gives_the_lists_of_two_pass_binning():
         assert torch.equal(rc.flatten_ids[:got[False]["n"]], got[False]["ids"])
 
 
+@pytest.mark.parametrize("case", ["all_culled", "single_gaussian", "odd_image", "huge_splats", "mostly_offscreen"])
+def test_render_context_edge_cases(case):
+    """RenderContext (binned projection, register sort, fused backward) on the inputs a tracker can meet at the edges:
+    nothing visible, one Gaussian, an image smaller than a tile grid cell and not a multiple of 16, splats that cover
+    every tile, a cloud that is mostly off screen -- render, alpha and the pose gradient against the float64 oracle."""
+    _gpu()
+    from gsplatloc_amd.context import RenderContext
+    gen = torch.Generator().manual_seed(11)
+    W, H, N, sigma, op = 96, 64, 600, 1.5, (0.3, 1.0)
+    if case == "odd_image":
+        W, H, N = 37, 21, 150
+    elif case == "single_gaussian":
+        N = 1
+    elif case == "huge_splats":
+        N, sigma, op = 40, 60.0, (0.05, 0.3)
+    sc = _scene32(N, W, H, sigma_px=sigma, opacity=op)
+    V = torch.linalg.inv(small_pose(0.7, 0.02, dtype=torch.float32))
+    if case == "all_culled":
+        sc["means"][:, 2] = -sc["means"][:, 2]          # behind the camera
+    elif case == "mostly_offscreen":
+        sc["means"][:, 0] += 0.8 * sc["means"][:, 2]    # shifted right: most of the cloud leaves the image
+    sh = sh_from_rgb(sc["rgbs"])
+    ins = [sc[k] for k in ("means", "quats", "scales", "opacities")] + [sh]
+    Vo = V.double()[None].clone().requires_grad_()
+    r_o, a_o, _ = G.rasterization(*[t.double() for t in ins], Vo, sc["K"].double()[None], W, H, sh_degree=1,
+                                  render_mode="RGB+ED")
+    rc = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, full_grads=True)
+    dev_in = [t.to(DEV).contiguous() for t in ins] + [V.to(DEV).contiguous(), sc["K"].to(DEV).contiguous()]
+    n = rc.calibrate(*dev_in)
+    render, alphas = rc.forward(*dev_in)
+    assert rc.check_capacity() == n
+    if case == "all_culled":
+        assert n == 0 and float(render.abs().max()) == 0.0 and float(alphas.abs().max()) == 0.0
+    else:
+        assert n > 0
+    if case == "huge_splats":
+        assert int((rc.offs[1:] - rc.offs[:-1]).min()) > 0   # every tile has a list
+    mostly_close(render[None], r_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="render")
+    mostly_close(alphas[None], a_o, rtol=1e-4, atol=2e-5, max_bad_frac=3e-3, what="alpha")
+    ok = agreeing_pixels(render[None], alphas[None], r_o, a_o)
+    v_c = torch.randn(r_o.shape, generator=gen) * ok[..., None]
+    v_a = torch.randn(a_o.shape, generator=gen) * ok[..., None]
+    ((r_o * v_c.double()).sum() + (a_o * v_a.double()).sum()).backward()
+    g = rc.backward(v_c[0].float().to(DEV).contiguous(), v_a[0].float().to(DEV).contiguous())
+    want = Vo.grad[0, :3]
+    if float(want.abs().max()) == 0.0:
+        assert float(g["viewmat"].abs().max()) == 0.0 and float(g["means"].abs().max()) == 0.0
+    else:
+        err = rel_inf(g["viewmat"][:3], want)
+        report(f"RenderContext edge case {case}", 1.0 - ok.double().mean().item(), v_viewmat=err)
+        assert err < POSE_GRAD_TOL, err
+    assert torch.isfinite(g["viewmat"]).all() and torch.isfinite(g["means"]).all()
+
+
 @pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB", True)])
 def test_deterministic_backward_is_bit_reproducible(mode, full):
     """RenderContext(deterministic=True): no float atomics in the backward (per-wave moment rows summed in wave order,

@@ -42,3 +42,18 @@ def test_compositing_kernels_keep_their_occupancy():
     assert det["ScratchSize"] == 0 and det["LDS"] <= 64 * 1024, det            # must not spill, two workgroups per CU
     fwd = [v for k, v in px.items() if "k_praster_fwdILi4ELb1" in k][0]
     assert fwd["ScratchSize"] == 0 and fwd["Occupancy"] >= 6, fwd
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_sort_and_projection_kernels_stay_in_registers():
+    binning = _resources("binning.hip")
+    sort = [v for k, v in binning.items() if "k_tile_sort" in k]
+    assert len(sort) == 1
+    s = sort[0]   # 32 keys per lane = 64 registers of keys: no spills, four waves per SIMD, LDS only for the long-list path
+    assert s["ScratchSize"] == 0 and s["Occupancy"] >= 4 and s["LDS"] <= 8 * 1024 + 64, s
+    fused = _resources("fused.hip")
+    for k, v in fused.items():
+        if "k_fproject" in k or "k_ftile_scan" in k:
+            assert v["ScratchSize"] == 0, (k, v)
+        if "k_fprojectILb" in k:   # forward projection (binned or not): 512-thread workgroups must fit twice per CU
+            assert v["VGPRs"] <= 128, (k, v)
