@@ -86,6 +86,19 @@ __global__ __launch_bounds__(256) void k_loss_fused(const float* __restrict__ re
         // Sobel taps: Kx[a][b] = (b-1)*(a==1?2:1)/8, Ky[a][b] = (a-1)*(b==1?2:1)/8 at offset (a-1, b-1); tap (a,b)
         // of pixel p reads clamp(p + (a-1, b-1)) and contributes to q when that equals q
         float acc = 0.f;
+        if (i > 0 && i < H - 1 && j > 0 && j < W - 1) {
+          // no tap is clamped onto a pixel that is not on the image border: plain transposed 3x3 correlation
+          // (tap (a,b) of p = q - (a-1, b-1) reads q; weights outside the owned rows are zero in swx / swy)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              float kx = (float)(b - 1) * (a == 1 ? 2.f : 1.f) * 0.125f;
+              float ky = (float)(a - 1) * (b == 1 ? 2.f : 1.f) * 0.125f;
+              if (kx != 0.f) acc += swx[ly + 2 - a][lx + 2 - b] * kx;
+              if (ky != 0.f) acc += swy[ly + 2 - a][lx + 2 - b] * ky;
+            }
+        } else
         for (int pi = max(i - 1, max(r0, 0)); pi <= min(i + 1, r1 - 1); ++pi)
           for (int pj = max(j - 1, 0); pj <= min(j + 1, W - 1); ++pj) {
             float wx = swx[pi - y0 + 1][pj - x0 + 1], wy = swy[pi - y0 + 1][pj - x0 + 1];
