@@ -505,6 +505,9 @@ def main():
                 "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
                 "launch": "hipGraph replay" if graph is not None else "eager",
                 "backward": backward_name(ctx),
+                "binning": ("keys written into per-tile bins by the projection kernel (sizes from calibrate()), "
+                            "register sort per tile" if getattr(ctx, "bins", None) is not None
+                            else "count, scan, scatter, register sort per tile"),
                 "staging": args.staging + (" records for compositing (T and accumulators f32)" if args.staging == "fp16" else ""),
             },
             "roofline": {
