@@ -246,8 +246,8 @@ def test_graph_tracker_early_stop():
 
 
 def test_graph_tracker_recovers_from_overflows():
-    """Neither a splat that outgrows the tiny backward nor an intersection list that outgrows its buffer costs the
-    frame: both are flagged on the device, read at the poll, and the frame is re-run from its initial pose with the
+    """Neither a splat that outgrows the tiny backward nor an intersection list that outgrows its buffer nor a tile
+    list that outgrows its bin costs the frame: all are flagged on the device, read at the poll, and the frame is re-run from its initial pose with the
     general backward / a larger buffer -- with the result of a tracker that had the right set-up from the start."""
     M, fp, K, pts0, pts1, scales0, scales1 = _setup()
     from gsplatloc_amd.graph_tracker import GraphTracker
@@ -265,8 +265,10 @@ def test_graph_tracker_recovers_from_overflows():
     assert gt.rc.tiny
     gt.scales.copy_(big)                        # ... which then grow: tiny overflow AND more intersections
     gt.rc._alloc_isects(int(gt.rc.n_is.item()) + 16)
+    gt.rc._alloc_bins(8)                        # ... and tile lists that outgrow their bins
     got = gt.run()
     assert not gt.rc.tiny and gt.rc.capacity > int(gt.rc.n_is.item())
+    assert gt.rc.bin_cap > 8 and gt.rc.bins_overflowed() == 0
     assert got.steps == want.steps == 30
     assert torch.allclose(torch.tensor(got.losses), torch.tensor(want.losses), rtol=1e-4)
 
