@@ -517,6 +517,72 @@ def test_render_context_edge_cases(case):
     assert torch.isfinite(g["viewmat"]).all() and torch.isfinite(g["means"]).all()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_render_context_against_the_oracle(seed):
+    """Randomised configurations of the fused path (render mode, SH degree, anti-aliasing, anisotropy, splat size,
+    opacity range, image size, tile-row strip, record staging, deterministic mode, near plane) against float64 autograd
+    of the oracle: render, alpha, pose gradient (1e-4, flip-aware) and the summed Gaussian gradients."""
+    _gpu()
+    from gsplatloc_amd.context import RenderContext
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(20, 200)), int(rng.integers(20, 140))
+    N = int(rng.integers(50, 3000))
+    mode = ["RGB+ED", "ED", "RGB", "D", "RGB+D"][int(rng.integers(0, 5))]
+    rgb = mode.startswith("RGB")
+    sh_deg = int(rng.integers(0, 4)) if rgb else 1
+    aa = bool(rng.integers(0, 2))
+    sigma = float(rng.choice([0.0, 0.6, 1.2, 2.5, 5.0]))
+    op = (float(rng.uniform(0.05, 0.5)), float(rng.uniform(0.6, 1.0)))
+    th = (H + 15) // 16
+    rows = None
+    if rng.integers(0, 3) == 0 and th >= 3:
+        r0 = int(rng.integers(0, th - 1))
+        rows = (r0, int(rng.integers(r0 + 1, th + 1)))
+    det = bool(rng.integers(0, 3) == 0)
+    near = float(rng.choice([0.01, 1.5]))
+    sc = _scene32(N, W, H, sigma_px=sigma, opacity=op, aniso=bool(rng.integers(0, 2)), seed=100 + seed)
+    gen = torch.Generator().manual_seed(seed)
+    K_sh = (sh_deg + 1) ** 2
+    colors = torch.randn(N, K_sh, 3, generator=gen) * 0.4 if rgb else None
+    V = torch.linalg.inv(small_pose(float(rng.uniform(0.0, 2.0)), float(rng.uniform(0.0, 0.05)), dtype=torch.float32))
+    kw = dict(sh_degree=sh_deg if rgb else None, width=W, height=H, packed=False, render_mode=mode, near_plane=near,
+              rasterize_mode="antialiased" if aa else "classic")
+    names = ("means", "quats", "scales", "opacities")
+    ins_o = [sc[k].double().clone().requires_grad_() for k in names]
+    col_o = colors.double().clone().requires_grad_() if rgb else sc["rgbs"].double()
+    Vo = V.double()[None].clone().requires_grad_()
+    r_o, a_o, _ = G.rasterization(*ins_o, col_o, Vo, sc["K"].double()[None], **kw)
+    rc = RenderContext(N, W, H, mode, sh_degree=sh_deg if rgb else None, K_sh=K_sh if rgb else 0, device=DEV,
+                       near_plane=near, antialiased=aa, tile_rows=rows, deterministic=det, full_grads=True)
+    dev_in = [sc[k].to(DEV).contiguous() for k in names] + [colors.to(DEV).contiguous() if rgb else None,
+                                                             V.to(DEV).contiguous(), sc["K"].to(DEV).contiguous()]
+    rc.calibrate(*dev_in)
+    render, alphas = rc.forward(*dev_in)
+    rc.check_capacity()
+    y0, y1 = (0, H) if rows is None else (rows[0] * 16, min(rows[1] * 16, H))
+    tag = f"fuzz {seed}: {mode} sh={sh_deg} aa={aa} sigma={sigma} {W}x{H} N={N} rows={rows} det={det} near={near}"
+    mostly_close(render[None, y0:y1], r_o[:, y0:y1], rtol=1e-4, atol=2e-5, max_bad_frac=5e-3, what=tag + " render")
+    mostly_close(alphas[None, y0:y1], a_o[:, y0:y1], rtol=1e-4, atol=2e-5, max_bad_frac=5e-3, what=tag + " alpha")
+    ok = agreeing_pixels(render[None], alphas[None], r_o, a_o)
+    ok[:, :y0] = False
+    ok[:, y1:] = False
+    v_c = torch.randn(r_o.shape, generator=gen) * ok[..., None]
+    v_a = torch.randn(a_o.shape, generator=gen) * ok[..., None]
+    loss_o = (r_o * v_c.double()).sum() + (a_o * v_a.double()).sum()
+    if not loss_o.requires_grad:
+        return
+    loss_o.backward()
+    g = rc.backward(v_c[0].float().to(DEV).contiguous(), v_a[0].float().to(DEV).contiguous())
+    want = Vo.grad[0, :3]
+    if float(want.abs().max()) > 0:
+        err = rel_inf(g["viewmat"][:3], want)
+        report(tag, 1.0 - ok[:, y0:y1].double().mean().item(), v_viewmat=err)
+        assert err < POSE_GRAD_TOL, (tag, err)
+    for nm, o_t in zip(names, ins_o):
+        if o_t.grad is not None and float(o_t.grad.abs().max()) > 0 and nm != "quats":
+            assert rel_inf(g[nm].sum(0), o_t.grad.sum(0)) < 2e-3, (tag, nm)
+
+
 @pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB", True)])
 def test_deterministic_backward_is_bit_reproducible(mode, full):
     """RenderContext(deterministic=True): no float atomics in the backward (per-wave moment rows summed in wave order,
