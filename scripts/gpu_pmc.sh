@@ -23,4 +23,3 @@ for k in sorted(agg, key=lambda k: -agg[k].get("SQ_WAVE_CYCLES", 0))[:9]:
     n = cnt[k]
     print(f"{k:40s} n={n:3d} " + " ".join(f"{c[3:]}={v / n:.3g}" for c, v in sorted(agg[k].items())))
 PY
-timeout -k 10 600 python -m pytest tests/test_gpu_configs.py -m gpu -q -s > gpurun_out/t_configs.log 2>&1; tail -3 gpurun_out/t_configs.log; grep "parity\]" gpurun_out/t_configs.log
