@@ -237,7 +237,7 @@ def cpu_baseline_torch(args, cores, V, reason):
 
 
 def backward_name(ctx):
-    return "tiny-splat slabs + 4-lane gather" if getattr(ctx, "tiny", False) else "quadrant walk + MFMA pixel sums"
+    return "tiny-splat slabs, folded inside the projection backward" if getattr(ctx, "tiny", False) else "quadrant walk + MFMA pixel sums"
 
 
 def event_stats(ms):
