@@ -13,7 +13,7 @@
 
 namespace gsl {
 
-#define GSL_SORT_LDS_CAP 1024  // keys per LDS block of the long-list sort (8 KiB: no occupancy cost for the wave sorts)
+#define GSL_SORT_LDS_CAP 4096  // keys per LDS block of the long-list sort (32 KiB: the wave sorts are limited to four workgroups per CU by their registers anyway)
 
 // Per-wave merged atomic add of 1 on ctr[key]: lanes holding the same key elect a leader.
 // Returns the position (old value + rank among equal lanes) for `active` lanes.
@@ -313,7 +313,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n, int tid) {
 // Lists longer than the LDS capacity (a pile of splats in one tile: e.g. the invalid pixels of a TUM depth frame,
 // which all sit at the previous camera's origin).  Same network, run block-wise: every stage k <= CAP is the LDS sort
 // of one aligned CAP-key block; of a stage k > CAP only the sub-steps at distance >= CAP touch global memory, the
-// remaining log2(CAP) sub-steps stay inside aligned blocks and run in LDS.  For n = 24 k: 15 global sub-steps
+// remaining log2(CAP) sub-steps stay inside aligned blocks and run in LDS.  For n = 24 k: 6 global sub-steps
 // instead of 120.
 __device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* lds, int tid) {
   constexpr int CAP = GSL_SORT_LDS_CAP;

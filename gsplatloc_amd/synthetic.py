@@ -132,3 +132,41 @@ def depth_frame_scene(W: int = 640, H: int = 480, stride: int = 1, holes: bool =
     quats = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device).repeat(N, 1).contiguous()
     return dict(means=pts, quats=quats, scales=scales.contiguous(), opacities=torch.ones(N, device=device), sh=sh, K=K,
                 W=W, H=H, N=N, viewmat=torch.linalg.inv(fp["c2w1"]).to(device).contiguous())
+
+
+def write_replica_sequence(root, W, H, n):
+    """Replica layout (results/depthNNNNNN.png at scale 6553.5, frameNNNNNN.jpg, traj.txt, cam_params.json) of a
+    camera drifting through the synthetic room: ~1 cm and ~0.4 deg between frames."""
+    import json
+
+    import numpy as np
+    from PIL import Image
+
+    d = root / "room0" / "results"
+    d.mkdir(parents=True)
+    K = replica_intrinsics(W, H)
+    cam = {"camera": {"w": W, "h": H, "fx": float(K[0, 0]), "fy": float(K[1, 1]), "cx": float(K[0, 2]),
+                      "cy": float(K[1, 2]), "scale": 6553.5}}
+    (root / "cam_params.json").write_text(json.dumps(cam))
+    rng = np.random.default_rng(5)
+    poses = []
+    c2w = np.eye(4)
+    for i in range(n):
+        if i:
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            th = np.radians(0.4)
+            Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+            step = np.eye(4)
+            step[:3, :3] = R
+            t = rng.normal(size=3)
+            step[:3, 3] = 0.01 * t / np.linalg.norm(t)
+            c2w = c2w @ step
+        depth = room_depth(W, H, K, torch.from_numpy(c2w).float()).numpy()
+        Image.fromarray(np.round(depth * 6553.5).astype(np.uint16)).save(d / f"depth{i:06d}.png")
+        Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(d / f"frame{i:06d}.jpg")
+        poses.append(c2w.copy())
+    with open(root / "room0" / "traj.txt", "w") as f:
+        for p in poses:
+            f.write(" ".join(f"{v:.12f}" for v in p.reshape(-1)) + "\n")

@@ -4,7 +4,7 @@ optimisation loop."""
 import pathlib, sys, tempfile, time
 import torch
 sys.path.insert(0, ".")
-from tests.test_gpu_eval import _write_sequence
+from gsplatloc_amd.synthetic import write_replica_sequence as _write_sequence
 from gsplatloc_amd.data.dataset import Parser
 from gsplatloc_amd.graph_tracker import GraphTracker
 from gsplatloc_amd.my_gsplat import TrackerConfig, init_gs_scales

@@ -49,8 +49,8 @@ def test_sort_and_projection_kernels_stay_in_registers():
     binning = _resources("binning.hip")
     sort = [v for k, v in binning.items() if "k_tile_sort" in k]
     assert len(sort) == 1
-    s = sort[0]   # 32 keys per lane = 64 registers of keys: no spills, four waves per SIMD, LDS only for the long-list path
-    assert s["ScratchSize"] == 0 and s["Occupancy"] >= 4 and s["LDS"] <= 8 * 1024 + 64, s
+    s = sort[0]   # 32 keys per lane = 64 registers of keys: no spills, four waves per SIMD, LDS (32 KB, five workgroups per CU: not the limiter) only for the long-list path
+    assert s["ScratchSize"] == 0 and s["Occupancy"] >= 4 and s["LDS"] <= 32 * 1024 + 64, s
     fused = _resources("fused.hip")
     for k, v in fused.items():
         if "k_fproject" in k or "k_ftile_scan" in k:
