@@ -193,13 +193,15 @@ class RenderContext:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
                                      ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, int(self.deterministic),
-                                     ptr(self.bins), self.bin_cap, current_stream()), "gsl_fused_bin")
+                                     ptr(self.bins), self.bin_cap, ptr(self.n_is), ptr(self.flags), current_stream()),
+              "gsl_fused_bin")
 
     def _raster_fwd(self) -> None:
         check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
-                                            ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh), current_stream()),
+                                            ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
+                                            ptr(self.ws) if self.bins is not None else None, current_stream()),
               "gsl_fused_raster_fwd")
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:

@@ -442,17 +442,62 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
 // Four tiles per 256-thread workgroup, one per wave; write flatten_ids (+ gsplat-style isect_ids, + the sorted keys
 // when the deterministic backward wants them).  The unsorted keys of a tile are its span of `keys`, or its
 // fixed-capacity bin (binned projection).
-__global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ tile_offsets, int tile_begin,
+// counts != nullptr (binned projection, launched over ALL tiles): tile_offsets is an OUTPUT -- every workgroup adds up
+// the sizes of the tiles before its own (a few coalesced loads per thread) and its waves write the offsets of their
+// tiles, the last one also the total; a tile that outgrew its bin keeps bin_cap entries and raises flags[1] (its size
+// goes to flags[2]).  The separate single-workgroup scan launch disappears; the counters are cleared later by the
+// compositing forward (every workgroup may still be reading them here).
+__global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_offsets, int tile_begin,
                                                    int n_strip_tiles, long long capacity,
                                                    uint64_t* __restrict__ keys, int32_t* __restrict__ flatten_ids,
                                                    int64_t* __restrict__ isect_ids, int64_t cam_enc,
-                                                   int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap) {
+                                                   int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap,
+                                                   const int32_t* __restrict__ counts, int32_t* __restrict__ n_isects,
+                                                   int32_t* __restrict__ flags) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
+  __shared__ int s_scan[8];
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (counts) {
+    int first = tile_begin + blockIdx.x * 4;
+    int acc = 0;
+    for (int i = tid; i < first; i += 256) acc += min(counts[i], bin_cap);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    int t_own = first + wv;
+    int c_own = (blockIdx.x * 4 + wv < n_strip_tiles) ? counts[t_own] : 0;
+    if (lane == 0) {
+      s_scan[wv] = acc;
+      s_scan[4 + wv] = min(c_own, bin_cap);
+      if (c_own > bin_cap && flags) { flags[1] = 1; atomicMax(&flags[2], c_own); }
+    }
+    __syncthreads();
+    int base = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    for (int w = 0; w < wv; ++w) base += s_scan[4 + w];
+    if (lane == 0 && blockIdx.x * 4 + wv < n_strip_tiles) {
+      tile_offsets[t_own] = base;
+      if (blockIdx.x * 4 + wv == n_strip_tiles - 1) {
+        tile_offsets[t_own + 1] = base + s_scan[4 + wv];
+        if (n_isects) n_isects[0] = base + s_scan[4 + wv];
+      }
+    }
+  }
+  // span of tile q of this workgroup in the packed arrays: from the scan above, or from the offsets given
+  auto span = [&](int q, long long& s, long long& e) {
+    int t = tile_begin + blockIdx.x * 4 + q;
+    if (counts) {
+      s = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+      for (int w = 0; w < q; ++w) s += s_scan[4 + w];
+      e = s + s_scan[4 + q];
+    } else {
+      s = tile_offsets[t];
+      e = tile_offsets[t + 1];
+    }
+  };
   int local = blockIdx.x * 4 + wv;
   if (local < n_strip_tiles) {
     int t = tile_begin + local;
-    long long s = tile_offsets[t], e = tile_offsets[t + 1];
+    long long s, e;
+    span(wv, s, e);
     if (e > capacity) e = capacity;
     int n = (int)max(e - s, (long long)0);
     if (bins && n > bin_cap) n = bin_cap;
@@ -472,7 +517,8 @@ __global__ __launch_bounds__(256) void k_tile_sort(const int32_t* __restrict__ t
     int lq = blockIdx.x * 4 + q;
     if (lq >= n_strip_tiles) break;
     int t = tile_begin + lq;
-    long long s = tile_offsets[t], e = tile_offsets[t + 1];
+    long long s, e;
+    span(q, s, e);
     if (e > capacity) e = capacity;
     int n = (int)max(e - s, (long long)0);
     if (bins && n > bin_cap) n = bin_cap;
@@ -611,24 +657,26 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc, 0,
-                     (uint64_t*)nullptr, 0);
+  hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     const_cast<int32_t*>(tile_offsets), tile_begin, n_strip_tiles, (long long)capacity, sort_keys,
+                     flatten_ids, isect_ids, cam_enc, 0, (uint64_t*)nullptr, 0, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
 
 // gsl_tile_sort that can also leave the sorted (depth bits, id) keys in sort_keys and read the unsorted keys from
 // fixed-capacity per-tile bins instead of sort_keys (internal: gsl_fused_bin)
-extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
-                                  int write_sorted_keys, uint64_t* bins, int bin_cap, void* stream) {
+                                  int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
+                                  int32_t* n_isects, int32_t* flags, void* stream) {
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
-  if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
-  if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
+  if (counts && (!bins || tile_begin != 0)) return GSL_ERR_BAD_ARG;  // the scan runs over all tiles, bins only
+  if (n_strip_tiles == 0 || (capacity == 0 && !counts)) return GSL_OK;
+  if (capacity > 0 && (!sort_keys || !flatten_ids)) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
                      tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
-                     write_sorted_keys, bins, bin_cap);
+                     write_sorted_keys, bins, bin_cap, counts, n_isects, flags);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -889,33 +889,40 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
 #undef CALL_P
     GSL_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(gsl::k_ftile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors,
-                     bins ? bin_cap : 0, flags);
+  if (bins) return GSL_OK;  // binned mode: gsl_fused_bin's sort kernel adds up the tile sizes itself
+  hipLaunchKernelGGL(gsl::k_ftile_scan, dim3(1), dim3(1024), 0, st, counts, n_tiles, tile_offsets, n_isects, cursors, 0,
+                     flags);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
 
 // defined in binning.hip
-extern "C" int gsl_tile_sort_keys(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
-                                  int write_sorted_keys, uint64_t* bins, int bin_cap, void* stream);
+                                  int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
+                                  int32_t* n_isects, int32_t* flags, void* stream);
 
 extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0, int ty1,
-                             int tile_n_bits, const int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
+                             int tile_n_bits, int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
                              int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes,
-                             int write_sorted_keys, void* bins, int bin_cap, void* stream) {
+                             int write_sorted_keys, void* bins, int bin_cap, int32_t* n_isects, int32_t* flags,
+                             void* stream) {
   if (N < 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0)
     return GSL_ERR_BAD_ARG;
   int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
   if (nst > GSL_F_MAX_STRIP_TILES || !tile_offsets) return GSL_ERR_BAD_ARG;
+  if (bins) {
+    // gsl_fused_project already put every key into its tile's bin and left the tile sizes in the counters: the sort
+    // kernel runs over ALL tiles, writes tile_offsets[n_tiles + 1] and n_isects itself (sizes outside the strip are 0)
+    if (bin_cap <= 0 || !n_isects) return GSL_ERR_BAD_ARG;
+    if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
+    if (capacity > 0 && (!sort_keys || !flatten_ids)) return GSL_ERR_BAD_ARG;
+    return gsl_tile_sort_keys(tile_offsets, 0, n_tiles, capacity, sort_keys, flatten_ids, isect_ids, 0,
+                              write_sorted_keys, (uint64_t*)bins, bin_cap, (const int32_t*)ws, n_isects, flags, stream);
+  }
   if (N == 0 || capacity == 0 || nst == 0) return GSL_OK;
   if (!Q0 || !radii || !sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   if (!ws || ws_bytes < gsl_fused_ws_bytes(N, n_tiles)) return GSL_ERR_WORKSPACE;
-  if (bins) {  // gsl_fused_project already put every key into its tile's bin
-    if (bin_cap <= 0) return GSL_ERR_BAD_ARG;
-    return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
-                              write_sorted_keys, (uint64_t*)bins, bin_cap, stream);
-  }
   hipStream_t st = (hipStream_t)stream;
   int32_t* cursors = (int32_t*)ws + n_tiles;
   hipLaunchKernelGGL(gsl::k_fscatter, dim3((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), dim3(GSL_F_BIN_THREADS),
@@ -923,7 +930,7 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
                      tile_offsets, cursors, (long long)capacity, sort_keys);
   GSL_CHECK_LAUNCH();
   return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
-                            write_sorted_keys, nullptr, 0, stream);
+                            write_sorted_keys, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \

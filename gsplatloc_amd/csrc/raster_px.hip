@@ -105,11 +105,14 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-    int row0, int row1, const uint4* __restrict__ Qh) {
+    int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ PStage<D> sb;
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
+  // projection (no clearing launch; sizes of tiles outside the strip are never raised)
+  if (clear_counts && threadIdx.x == 0) clear_counts[tile] = 0;
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
@@ -416,7 +419,7 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
 extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
-                                 int32_t* last_ids, int row0, int row1, const void* Qh, void* stream) {
+                                 int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -431,7 +434,8 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
 #define CALL_PF(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh)
+                     flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
+                     (int32_t*)binned_ws)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();

@@ -70,7 +70,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_bin(ptr(Q0), ptr(radii), N, tw, th, ty0, ty1, tile_n_bits(n_tiles), ptr(offs), n_isects,
                                 ptr(keys), ptr(flatten_ids) if n_isects else None,
                                 ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, 0, None, 0,
-                                st), "gsl_fused_bin")
+                                None, None, st), "gsl_fused_bin")
         render = torch.zeros(H, W, D, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, D, dtype=f32, device=dev)
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
@@ -78,7 +78,7 @@ class _FusedRasterization(torch.autograd.Function):
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
-                                       ptr(last_ids), 0, H, None, st), "gsl_fused_raster_fwd")
+                                       ptr(last_ids), 0, H, None, None, st), "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
                               comps if antialiased else torch.empty(0, device=dev), offs, flatten_ids, render,

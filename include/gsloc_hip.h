@@ -173,10 +173,13 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     list is found by binary search).  Bit-identical gradients run to run.
  * Binned mode (bins, may be NULL): when the caller knows an upper bound of a tile's list length (a tracker renders the
  *                     same Gaussians hundreds of times per frame), gsl_fused_project given bins[n_tiles][bin_cap]
- *                     (uint64) writes every (depth bits << 32 | id) key straight into its tile's bin and
- *                     gsl_fused_bin given the same bins only sorts: the scatter pass, its second read of the
- *                     records and the counter-clearing launch disappear.  ws must be zero-filled once before the
- *                     first call (every call leaves its counters cleared).  A tile that outgrows bin_cap keeps its
+ *                     (uint64) writes every (depth bits << 32 | id) key straight into its tile's bin and leaves
+ *                     the tile sizes in ws (it does NOT write tile_offsets / n_isects then); gsl_fused_bin given the
+ *                     same bins adds the sizes up inside its sort kernel -- tile_offsets[n_tiles + 1] and n_isects
+ *                     are its OUTPUTS in this mode -- and sorts; gsl_fused_raster_fwd given binned_ws = ws clears
+ *                     the counters for the next projection.  The three calls belong together: the scatter pass,
+ *                     its second read of the records, the scan launch and the counter-clearing launch disappear.
+ *                     ws must be zero-filled once before the first call.  A tile that outgrows bin_cap keeps its
  *                     first bin_cap entries, raises flags[1] = 1 and leaves the largest count in flags[2]
  *                     (flags: 4 ints, may be NULL): poll it and re-run with larger bins.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
@@ -198,14 +201,15 @@ int gsl_fused_project(const float* means, const float* quats, const float* scale
                       int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
                       size_t ws_bytes, void* Qh, void* bins, int bin_cap, int32_t* flags, void* stream);
 int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0,
-                  int ty1, int tile_n_bits, const int32_t* tile_offsets, int64_t capacity,
+                  int ty1, int tile_n_bits, int32_t* tile_offsets, int64_t capacity,
                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
-                  size_t ws_bytes, int write_sorted_keys, void* bins, int bin_cap, void* stream);
+                  size_t ws_bytes, int write_sorted_keys, void* bins, int bin_cap, int32_t* n_isects,
+                  int32_t* flags, void* stream);
 int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
-                         void* stream);
+                         void* binned_ws, void* stream);
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
