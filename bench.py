@@ -101,15 +101,16 @@ def algorithmic_bytes(N, I, P, D, n_tiles, full):
 
 
 def implementation_bin_bytes(N, I, n_tiles):
-    """What THIS build's binning moves (no credit for radix passes it does not run): the scatter reads a 16-byte
-    record and a radius per Gaussian and writes one 8-byte key per intersection; the per-tile sort reads the keys
-    and writes the 4-byte Gaussian ids; counts, offsets and cursors are 12 bytes per tile."""
-    return N * 20 + I * (8 + 8 + 4) + n_tiles * 12
+    """What THIS build's binning moves (no credit for radix passes it does not run): the projection kernel writes
+    one 8-byte key per intersection into its tile's bin; the per-tile sort reads the keys and writes the 4-byte
+    Gaussian ids; tile sizes and offsets are 8 bytes per tile.  (The two-pass path of the drop-in API also re-reads
+    a 16-byte record and a radius per Gaussian in its scatter pass: N * 20 more.)"""
+    return I * (8 + 8 + 4) + n_tiles * 8
 
 
 STAGE_KERNELS = {  # stage timer -> kernels it brackets (names as rocprofv3 prints them, template arguments dropped)
-    "project_fwd": ("k_fproject<",), "bin": ("k_ftile_scan", "k_fscatter", "k_tile_sort"),
-    "raster_fwd": ("k_praster_fwd",), "raster_bwd": ("k_mraster_bwd", "k_tiny_bwd", "k_tiny_gather"),
+    "project_fwd": ("k_fproject<true, true>", "k_fproject<false, true>"), "bin": ("k_tile_sort",),
+    "raster_fwd": ("k_praster_fwd",), "raster_bwd": ("k_mraster_bwd", "k_tiny_bwd"),
     "project_bwd": ("k_fproject_bwd", "k_freduce_viewmat"),
 }
 

@@ -3,8 +3,8 @@
 Same arithmetic as ``Runner.train``'s inner loop (/root/reference/src/my_gsplat/gs_trainer_total.py:79-267)
 and as ``my_gsplat.PoseTracker``; the difference is where the glue runs: the loss (loss.py:10-59), the pose
 chain (model.py:79-82, transform.py:50-66, geometry.py:12-20), both Adam optimisers, the exponential LR
-decay and the early-stop bookkeeping (data/base.py:34-43) live in three device kernels
-(csrc/tracker.hip), so one iteration is a fixed sequence of ~13 launches with no allocation and no host
+decay and the early-stop bookkeeping (data/base.py:34-43) live in two device kernels (loss, pose step:
+csrc/tracker.hip), so one iteration is a fixed sequence of 7 launches with no allocation and no host
 synchronisation, replayed as a HIP graph.  The host looks at the device-side "stopped" flag every
 ``poll`` iterations only.
 

@@ -369,7 +369,7 @@ def test_fused_tile_strip_matches_full_render():
 
 @pytest.mark.parametrize("mode,full", [("RGB+ED", True), ("ED", False), ("RGB+ED", False), ("RGB", True)])
 def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
-    """RenderContext picks the tiny-splat backward (4x4 record slabs, 4-lane gather, no atomics) when r_cull < 2 px;
+    """RenderContext picks the tiny-splat backward (4x4 record slabs folded inside the projection backward, no atomics) when r_cull < 2 px;
     its gradients must agree with the general compositing backward (quadrant walk, MFMA pixel sums) on the same
     render."""
     A = _gpu()
