@@ -170,3 +170,50 @@ def write_replica_sequence(root, W, H, n):
     with open(root / "room0" / "traj.txt", "w") as f:
         for p in poses:
             f.write(" ".join(f"{v:.12f}" for v in p.reshape(-1)) + "\n")
+
+
+def write_tum_sequence(root, W, H, n, hole_frac: float = 0.06, crop_edge: int = 8, name: str = "freiburg1_desk"):
+    """TUM RGB-D layout (rgbd_dataset_<name>/{rgb/*.png, depth/*.png at scale 5000, rgb.txt, depth.txt, groundtruth.txt
+    with `timestamp tx ty tz qx qy qz qw`, cam_params.json with crop_edge}) of the same drifting camera, 15 Hz, the
+    depth and pose timestamps a few milliseconds off the colour ones, and rectangular patches of INVALID (zero) depth
+    in every frame as a Kinect frame has them."""
+    import json
+
+    import numpy as np
+    from PIL import Image
+    from scipy.spatial.transform import Rotation
+
+    d = root / f"rgbd_dataset_{name}"
+    (d / "rgb").mkdir(parents=True)
+    (d / "depth").mkdir()
+    K = replica_intrinsics(W, H)
+    cam = {"camera": {"w": W, "h": H, "fx": float(K[0, 0]), "fy": float(K[1, 1]), "cx": float(K[0, 2]),
+                      "cy": float(K[1, 2]), "scale": 5000.0, "crop_edge": crop_edge}}
+    (d / "cam_params.json").write_text(json.dumps(cam))
+    rng = np.random.default_rng(9)
+    c2w = np.eye(4)
+    t0 = 1305031450.0
+    with open(d / "rgb.txt", "w") as fr, open(d / "depth.txt", "w") as fd, open(d / "groundtruth.txt", "w") as fg:
+        fr.write("# color images\n")
+        fd.write("# depth maps\n")
+        fg.write("# timestamp tx ty tz qx qy qz qw\n")
+        for i in range(n):
+            if i:
+                ax = rng.normal(size=3)
+                ax /= np.linalg.norm(ax)
+                step = np.eye(4)
+                step[:3, :3] = Rotation.from_rotvec(np.radians(0.4) * ax).as_matrix()
+                t = rng.normal(size=3)
+                step[:3, 3] = 0.01 * t / np.linalg.norm(t)
+                c2w = c2w @ step
+            depth = room_depth(W, H, K, torch.from_numpy(c2w).float()).numpy()
+            for _ in range(int(hole_frac * W * H / (24 * 18))):
+                x0, y0 = int(rng.integers(0, W - 24)), int(rng.integers(0, H - 18))
+                depth[y0:y0 + 18, x0:x0 + 24] = 0.0
+            ts = t0 + i / 15.0
+            Image.fromarray(np.round(depth * 5000.0).astype(np.uint16)).save(d / "depth" / f"{ts:.6f}.png")
+            Image.fromarray(rng.integers(0, 255, (H, W, 3), dtype=np.uint8)).save(d / "rgb" / f"{ts:.6f}.png")
+            q = Rotation.from_matrix(c2w[:3, :3]).as_quat()  # x y z w
+            fr.write(f"{ts:.6f} rgb/{ts:.6f}.png\n")
+            fd.write(f"{ts + 0.004:.6f} depth/{ts:.6f}.png\n")
+            fg.write(f"{ts + 0.002:.6f} {c2w[0, 3]:.9f} {c2w[1, 3]:.9f} {c2w[2, 3]:.9f} {q[0]:.9f} {q[1]:.9f} {q[2]:.9f} {q[3]:.9f}\n")
