@@ -7,12 +7,13 @@ the reference's call, /root/reference/src/my_gsplat/model.py:195-213) -> backwar
 depth-channel gradient to every Gaussian input and to the 4x4 view matrix.  Inputs are resident
 in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload R|S|T|X]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload R|S|T|X|D]
 
 Workloads (SURVEY.md 8d / BASELINE.json configs): R (default, the metric's configuration) = 1 M random Gaussians,
 1200x680, sigma_px = 1; X = 5 M random Gaussians, 1920x1080; S = a 640x480 depth frame back-projected to 102 400
 Gaussians with the reference's as-coded kNN scales; T = one Gaussian per pixel of a 640x480 depth frame with
-invalid (zero) depths, 307 200 Gaussians.
+invalid (zero) depths, 307 200 Gaussians; D = one Gaussian per pixel of a 1200x680 depth frame, 816 000 Gaussians, as-coded
+scales (the reference's own regime at R size).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): screen-tile rows are
 split across ranks, every rank renders and back-propagates its strip, and the 12+4 pose-gradient floats are
@@ -31,6 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Idle OpenMP workers (torch's CPU ops, the CPU oracle of the cpu_baseline leg) must sleep, not spin: on a GPU box the
+# job owns a CPU *share* (a cgroup quota) of a much larger host, and a few hundred spinning workers burn the quota of a
+# scheduler period in a few milliseconds -- the whole process, the thread that launches the HIP graphs included, is
+# then frozen until the next period (~85 ms stalls between graph replays: DESIGN.md section 6).
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
 import torch  # noqa: E402
 
 WORKLOADS = {
@@ -38,6 +46,9 @@ WORKLOADS = {
     "X": dict(n=5_000_000, width=1920, height=1080, sigma_px=1.0, order="random", kind="random"),
     "S": dict(n=102_400, width=640, height=480, kind="depth_frame", stride=3, holes=False),
     "T": dict(n=307_200, width=640, height=480, kind="depth_frame", stride=1, holes=True),
+    # the reference's own regime at R size: one Gaussian per pixel of a 1200x680 Replica depth frame, raster order,
+    # as-coded kNN^2 scales (sigma_px -> 0): ref/src/data/Image.py:29,35, my_gsplat/geometry.py:60-64, cam_params.json:3-4
+    "D": dict(n=816_000, width=1200, height=680, kind="depth_frame", stride=1, holes=False),
 }
 PMC_SUMMARY = os.path.join("profiles", "r02_pmc_traffic.json")
 
@@ -77,6 +88,38 @@ def parse():
     if args.staging is None:
         args.staging = "fp16" if (args.workload == "X" and not explicit) else "fp32"
     return args
+
+
+def host_cpu_share():
+    """CPUs this process may really use: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def throttle_stats():
+    """(nr_throttled, throttled ms) of this process's cgroup, or None: how often the scheduler froze the job for
+    having used up its CPU quota."""
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            kv = dict(line.split()[:2] for line in open(path) if len(line.split()) >= 2)
+            us = int(kv.get("throttled_usec", 0)) or int(kv.get("throttled_time", 0)) // 1000
+            return int(kv.get("nr_throttled", 0)), us / 1e3
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def trace(msg):
@@ -147,7 +190,7 @@ def cpu_baseline(args, scene, gpu):
     the oracle's float64 build (the `parity` object): images on all pixels, the pose gradient flip-aware (upstream
     gradient zeroed where the two renders disagree beyond the image tolerance).  If the C library cannot be built,
     the PyTorch oracle on a same-density subsample is timed instead and says so."""
-    cores = os.cpu_count() or 1
+    cores = host_cpu_share()  # not os.cpu_count(): the box gives the job a CPU share of a much larger host
     V = scene["viewmat"].cpu()
     try:
         from oracle import c_oracle
@@ -158,14 +201,14 @@ def cpu_baseline(args, scene, gpu):
     arrays = [scene[k].cpu().numpy() for k in ("means", "quats", "scales", "opacities", "sh")] + [V.numpy(), scene["K"].cpu().numpy()]
     v = gpu["v_render"].cpu().numpy()
 
-    def step(precision="f32", v_render=v, threads=cores):
+    def step(precision="f32", v_render=v, threads=min(cores, 64)):
         return c_oracle.rasterization(*arrays, w, h, sh_degree=1, render_mode="RGB+ED", v_render=v_render,
                                       precision=precision, threads=threads)
 
-    # the port's OpenMP loops do not scale to every core of a large host: time a few thread counts (one warm-up and
-    # two timed steps each) and report the fastest, with the thread count it used
+    # the port's OpenMP loops do not scale to every core of a large host: time a few thread counts within the job's CPU
+    # share (one warm-up and two timed steps each) and report the fastest, with the thread count it used
     best = None
-    for threads in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
+    for threads in sorted({min(cores, 64), min(cores, 16)}, reverse=True):
         step(threads=threads)
         for _ in range(2):
             t = time.perf_counter()
@@ -175,8 +218,8 @@ def cpu_baseline(args, scene, gpu):
                 best = (d, threads)
     dt, used = best
     base = {"value": n / dt, "unit": "Gaussians/s", "cores": used, "kind": "port",
-            "sample": f"oracle/csrc/gsplat_oracle.c float32 + OpenMP, fastest of {{all, 64, 16}} threads on a {cores}-core "
-                      f"host = {used} threads, the full workload (N={n}, {w}x{h}, {out['n_isects']} intersections), "
+            "sample": f"oracle/csrc/gsplat_oracle.c float32 + OpenMP, fastest of {{64, 16}} threads within the job's CPU share "
+                      f"({cores} of the host's {os.cpu_count()} cores) = {used} threads, the full workload (N={n}, {w}x{h}, {out['n_isects']} intersections), "
                       f"fwd+bwd with all gradients, best of 2 after one warm-up step, {dt:.2f} s/step"}
     parity = None
     if gpu.get("render") is not None:
@@ -250,13 +293,20 @@ def event_stats(ms):
     return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": len(s)}
 
 
-def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
-    """Side measurement: the same step on another variant of the workload (graph replay, all gradients)."""
+def variant_rate(dev, N, W, H, sigma_px, order, steps=100, warmup=5, depth_frame=False):
+    """Side measurement: the same step on another variant of the workload (graph replay, all gradients).  Per-step HIP
+    events, median over `steps` replays (a wall-clock mean over a handful of replays cannot tell one host stall from a
+    slow kernel); the wall-clock mean is reported next to it.  depth_frame: workload D (one Gaussian per pixel of a
+    W x H depth frame, as-coded scales) instead of the random-N scene."""
     from gsplatloc_amd.context import RenderContext
-    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+    from gsplatloc_amd.synthetic import depth_frame_scene, perturbed_pose, random_scene
 
-    sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev, order=order)
-    viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    if depth_frame:
+        sc = depth_frame_scene(W, H, stride=1, holes=False, device=dev)
+        viewmat, N = sc["viewmat"], sc["N"]
+    else:
+        sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev, order=order)
+        viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
     K = sc["K"].contiguous()
     ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
     inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
@@ -279,17 +329,29 @@ def variant_rate(dev, N, W, H, sigma_px, order, steps=15, warmup=3):
         with torch.cuda.graph(graph, stream=side):
             step()
     torch.cuda.synchronize()
+    t = time.perf_counter()
     for _ in range(warmup):
         graph.replay()
     torch.cuda.synchronize()
+    warm_wall = (time.perf_counter() - t) / max(warmup, 1)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t = time.perf_counter()
-    for _ in range(steps):
+    for e0, e1 in events:
+        e0.record()
         graph.replay()
+        e1.record()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / steps
+    wall = (time.perf_counter() - t) / steps
     ctx.check_capacity()
-    return {"sigma_px": sigma_px, "order": order, "intersections_per_gaussian": n_is / N, "ms_per_step": dt * 1e3,
-            "gaussians_per_s": N / dt, "backward": backward_name(ctx)}
+    ev = event_stats([a.elapsed_time(b) for a, b in events])
+    ev["max"] = max(a.elapsed_time(b) for a, b in events)
+    dt = ev["median"] * 1e-3
+    return {"workload": f"D: {N} Gaussians of a {W}x{H} depth frame, as-coded scales" if depth_frame else "random-N",
+            "sigma_px": None if depth_frame else sigma_px, "order": "raster" if depth_frame else order,
+            "intersections_per_gaussian": n_is / N, "ms_per_step": ev["median"],
+            "step_ms_hip_events": ev, "ms_per_step_wall_mean": wall * 1e3, "warmup_ms_per_step_wall_mean": warm_wall * 1e3,
+            "gaussians_per_s": N / dt,
+            "backward": backward_name(ctx)}
 
 
 def pose_opt_rate(dev):
@@ -341,6 +403,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.set_num_threads(min(host_cpu_share(), 16))  # host-side torch ops are tiny here; never one thread per host core
+    throttle0 = throttle_stats()
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -557,6 +621,11 @@ def main():
             # reference's as-coded kNN scales; "raster" is the Gaussian order of a back-projected depth frame
             out["variants"] = [guarded(variant_rate, dev, args.n, W, H, s_, o_) for s_, o_ in
                                ((1.0, "raster"), (0.0, "random"), (0.0, "raster"))]
+            out["variants"].append(guarded(variant_rate, dev, W * H, W, H, 0.0, "raster", depth_frame=True))
+        th1 = throttle_stats()
+        out["host"] = {"cpu_share": host_cpu_share(), "host_cores": os.cpu_count(),
+                       "cgroup_throttled": None if (throttle0 is None or th1 is None) else
+                       {"periods": th1[0] - throttle0[0], "ms": th1[1] - throttle0[1]}}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

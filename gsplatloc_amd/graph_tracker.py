@@ -218,6 +218,22 @@ class GraphTracker:
             dst.copy_(src)
 
     # ------------------------------------------------------------------ frame loop
+    def _poll(self) -> Tuple[int, int, int, int]:
+        """The only host sync of the loop: (stopped, intersections beyond the capacity or 0, a splat outgrew the tiny
+        backward, longest tile list that outgrew its bin or 0).  With several ranks the four numbers are MAX-reduced
+        over the group, so every rank takes the same decision at the same iteration: a rank that re-ran the frame on
+        its own while the others returned would pair its all-reduces with those of a different iteration or frame."""
+        n_is = int(self.rc.n_is.item())
+        local = [int(self.pose_i[2].item()), n_is if n_is > self.rc.capacity else 0, int(self.rc.tiny_overflowed()),
+                 int(self.rc.bins_overflowed())]
+        if self.group is None:
+            return tuple(local)
+        import torch.distributed as dist
+        on_device = self.reduce_buf.is_cuda and dist.get_backend(self.group) != "gloo"
+        t = torch.tensor(local, dtype=torch.int64, device=self.dev if on_device else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return tuple(int(x) for x in t.tolist())
+
     def run(self) -> TrackResult:
         """Optimise the loaded frame until early stop or max_steps.  Returns the reference's read-outs."""
         start = [t.clone() for t in self._state()]
@@ -230,21 +246,23 @@ class GraphTracker:
                 for _ in range(n):
                     self._iteration()
                 done += n
-                # the only host sync: stopped flag, intersection count, overflow flags (tiny backward, tile bins)
-                stopped, n_is, tiny_over = int(self.pose_i[2].item()), int(self.rc.n_is.item()), self.rc.tiny_overflowed()
-                bin_over = self.rc.bins_overflowed()
-                if n_is > self.rc.capacity or tiny_over or bin_over:
+                stopped, n_over, tiny_over, bin_over = self._poll()
+                if n_over or tiny_over or bin_over:
                     redo = True
                     break
                 if stopped:
                     break
             if not redo:
                 break
-            # recover: iterations since the last poll ran on truncated lists or a dropped gradient
+            # recover: iterations since the last poll ran on truncated lists or a dropped gradient.  Every rank of a
+            # group arrives here together (the decision was reduced); the backward variant is switched on all of
+            # them, the rank-local buffers grow where they were too small.
             if tiny_over:
                 self.rc.use_general_backward()
-            if bin_over:
-                self.rc.grow_bins(bin_over)
+            own_bins = self.rc.bins_overflowed()
+            if own_bins:
+                self.rc.grow_bins(own_bins)
+            n_is = int(self.rc.n_is.item())
             if n_is > self.rc.capacity:
                 self.headroom *= 1.5
                 self.rc._alloc_isects(int(n_is * self.headroom) + 1024)

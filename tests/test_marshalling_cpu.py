@@ -250,3 +250,41 @@ def test_graph_tracker_group_mode_over_gloo(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
+
+
+GROUP_OVERFLOW = GROUP_RANK[:GROUP_RANK.index("# what gsl_pack_pose_reduce would have left")] + """
+# an overflow on ONE strip only (rank 1: a splat outgrew the tiny backward): the decision is MAX-reduced at the poll,
+# so both ranks re-run the frame together, both switch to the general backward, and their collectives stay paired
+gt.use_graph = False
+gt.rc.tiny = True
+if rank == 1:
+    gt.rc.flags[0] = 1
+n_coll = [0]
+real = gt._collective
+def counted():
+    n_coll[0] += 1
+    real()
+gt._collective = counted
+res = gt.run()
+assert n_coll[0] == 10, n_coll          # 5 iterations, recovery, 5 iterations again -- on BOTH ranks
+assert gt.rc.tiny is False and int(gt.rc.flags[0]) == 0
+print(f"rank {rank} ok", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_graph_tracker_overflow_on_one_rank_is_recovered_by_all(tmp_path):
+    """the overflow recovery must not be decided from rank-local state.  Two gloo ranks, the sticky
+    tiny-backward flag raised on rank 1 only: both ranks redo the frame (10 collectives each) and finish together."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "group_overflow.py"
+    script.write_text(GROUP_OVERFLOW)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29548", str(script), root]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
