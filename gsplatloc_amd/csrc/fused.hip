@@ -11,6 +11,9 @@
 //   Q0 = (x, y, depth, opacity_eff)   Q1 = (conic_a, conic_b, conic_c, r_cull)   Q2 = (r, g, b, 0)
 // r_cull is a conservative radius of the alpha >= 1/255 region, used by the per-quadrant ballot test.
 // gsplat's meta tensors (means2d, depths, conics, opacities) are strided views of Q0/Q1 on the host.
+#include <stdlib.h>
+#include <string.h>
+
 #include "project_dev.h"
 #include "sh_dev.h"
 
@@ -19,13 +22,21 @@ namespace gsl {
 #define GSL_F_BIN_THREADS 512
 #define GSL_F_MAX_STRIP_TILES 8192
 
+// Radius of the smallest disc around the centre that holds the whole alpha >= 1/255 ellipse {sigma <= tau}:
+// sqrt(2 tau / lambda_min(conic)).  (Round 2 stored the half-extent of the ellipse's axis-aligned bounding box, which is
+// smaller for a rotated anisotropic splat; every user treats the value as conservative -- the forward's pixel boxes,
+// the quadrant tests, the 4x4 slabs of the tiny backward -- and the 16-lane-group backward tests the DISC against its
+// 4x4 pixel blocks.  Identical for isotropic splats, GsplatLoc's only kind.)
 __device__ __forceinline__ float cull_radius(float ca, float cb, float cc, float op) {
   float tau = __logf(255.f * op) * 1.01f + 0.01f;
   float det = ca * cc - cb * cb;
   if (!(tau > 0.f)) return -1.f;  // opacity < 1/255: can never reach the alpha threshold
   if (!(det > 0.f) || !(ca > 0.f) || !(cc > 0.f)) return 1e30f;  // degenerate conic: never cull
-  float inv = 2.f * tau / det;
-  return sqrtf(inv * fmaxf(ca, cc)) * 1.0001f + 1e-3f;
+  float hd = 0.5f * (ca - cc);
+  float root = sqrtf(hd * hd + cb * cb);
+  float lmin = det / (0.5f * (ca + cc) + root);  // = mean - root, without the cancellation
+  if (!(lmin > 0.f)) return 1e30f;
+  return sqrtf(2.f * tau / lmin) * 1.0001f + 1e-3f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -933,6 +944,14 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
                             write_sorted_keys, nullptr, 0, nullptr, nullptr, nullptr, stream);
 }
 
+// defined in raster_g16.hip
+extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                                         int height, int tile_w, int ty0, int ty1, const int32_t* tile_offsets,
+                                         const int32_t* flatten_ids, int64_t capacity, const float* render,
+                                         const float* alphas, const int32_t* last_ids, const float* v_render,
+                                         const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
+                                         void* stream);
+
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
   else if (D == 3) { CALL(3, false); }                          \
@@ -969,6 +988,11 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
     GSL_CHECK_LAUNCH();
     return GSL_OK;
   }
+  // default: 16-lane-group walk (raster_g16.hip); GSLOC_BWD_KERNEL=mfma selects the quadrant walk + MFMA sums (dev switch)
+  static const bool use_mfma = [] { const char* e = getenv("GSLOC_BWD_KERNEL"); return e && !strcmp(e, "mfma"); }();
+  if (!use_mfma)
+    return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
+                                     capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh, stream);
 #define CALL_MB(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, false>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,   \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \

@@ -1,0 +1,63 @@
+"""Speed guards: the reference's own regime -- sub-pixel splats of a back-projected depth frame,
+sigma_px -> 0, raster order -- at R size must stay well below 1 ms per forward + backward step.  Median of per-step HIP
+events over graph replays (a wall-clock mean would also catch host stalls, which are not the kernels' business:
+profiles/r03_sigma0_stall_diagnosis.txt).  Measured on MI355X in round 3: 0.36 ms (raster), 0.50 ms (random order),
+0.32 ms (workload D); the bound leaves 2x head-room for slower boxes."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _median_step_ms(ctx, inp, v, va, steps=60):
+    def step():
+        ctx.forward(*inp)
+        ctx.backward(v, va, full=True)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        graph.replay()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in ev:
+        a.record()
+        graph.replay()
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    ctx.check_capacity()
+    return ms[len(ms) // 2]
+
+
+@pytest.mark.parametrize("kind,order,bound_ms", [("random-N", "raster", 1.0), ("random-N", "random", 1.0),
+                                                 ("depth-frame", "raster", 1.0)])
+def test_sigma0_step_at_R_size_stays_below_1ms(kind, order, bound_ms):
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene, perturbed_pose, random_scene
+
+    dev = torch.device("cuda")
+    W, H = 1200, 680
+    if kind == "depth-frame":
+        sc = depth_frame_scene(W, H, stride=1, holes=False, device=dev)
+        V = sc["viewmat"]
+    else:
+        sc = random_scene(1_000_000, W, H, sigma_px=0.0, device=dev, order=order)
+        V = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    N = sc["means"].shape[0]
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], V, sc["K"].contiguous())
+    ctx.calibrate(*inp)
+    assert ctx.tiny, "sub-pixel splats must select the tiny-splat backward"
+    g = torch.Generator().manual_seed(1)
+    v = torch.zeros(H, W, 4)
+    v[..., 3] = torch.randn(H, W, generator=g)
+    ms = _median_step_ms(ctx, inp, v.to(dev), torch.zeros(H, W, 1, device=dev))
+    print(f"[perf] {kind} {order}: N={N}, median step {ms:.3f} ms (bound {bound_ms})")
+    assert ms < bound_ms, f"{kind}/{order}: {ms:.3f} ms per step"
