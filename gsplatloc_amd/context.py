@@ -95,7 +95,7 @@ class RenderContext:
         self.flags = torch.zeros(4, dtype=i32, device=dev)
         self.bins, self.bin_cap = None, 0
         self.trec = self.vcT = None
-        self.keys = self.flatten_ids = None
+        self.keys = self.flatten_ids = self.hits = None
         if capacity is not None:
             self._alloc_isects(int(capacity))
         self._inputs = None
@@ -105,6 +105,8 @@ class RenderContext:
         self.capacity = max(int(capacity), 1)
         self.keys = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
         self.flatten_ids = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
+        # per list entry: the blocks of its tile that composited it (written by the forward, read by the backward)
+        self.hits = torch.zeros(self.capacity, dtype=torch.int16, device=self.device)
         if self.deterministic:
             self.vrow = torch.zeros(self.capacity, 16, dtype=torch.float32, device=self.device)
 
@@ -201,7 +203,8 @@ class RenderContext:
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
-                                            ptr(self.ws) if self.bins is not None else None, current_stream()),
+                                            ptr(self.ws) if self.bins is not None else None, ptr(self.hits),
+                                            current_stream()),
               "gsl_fused_raster_fwd")
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
@@ -214,7 +217,7 @@ class RenderContext:
             # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
-                                                ptr(self.vrow), current_stream()), "gsl_fused_raster_bwd")
+                                                ptr(self.vrow), ptr(self.hits), current_stream()), "gsl_fused_raster_bwd")
 
     def _project_bwd(self, full: bool, reduce: bool = True) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs

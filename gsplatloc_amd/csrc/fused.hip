@@ -950,7 +950,7 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const int32_t* flatten_ids, int64_t capacity, const float* render,
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                         void* stream);
+                                         const uint16_t* isect_hits, void* stream);
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
@@ -965,7 +965,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                    const float* render, const float* alphas, const int32_t* last_ids,
                                    const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                                   const void* Qh, float* vrow, void* stream) {
+                                   const void* Qh, float* vrow, const uint16_t* isect_hits, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -992,7 +992,8 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   static const bool use_mfma = [] { const char* e = getenv("GSLOC_BWD_KERNEL"); return e && !strcmp(e, "mfma"); }();
   if (!use_mfma)
     return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
-                                     capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh, stream);
+                                     capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
+                                     isect_hits, stream);
 #define CALL_MB(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, false>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,   \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \

@@ -118,7 +118,7 @@ __device__ __forceinline__ void graster_bwd_body(
     GStage<D, CG>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
     const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs,
     long long re, int tid, float px, float py, float tx0, float ty0, bool inside, int bin_final, float T_final,
-    const float (&vc)[D], float va, const int* __restrict__ bfinal) {
+    const float (&vc)[D], float va, const int* __restrict__ bfinal, const uint16_t* __restrict__ isect_hits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   constexpr int NV = GStage<D, CG>::NV;
@@ -127,7 +127,7 @@ __device__ __forceinline__ void graster_bwd_body(
   constexpr int LCAP = GStage<D, CG>::LCAP;
   static_assert(16 * LCAP * NS >= GSL_GBS * 16, "the packed gradient rows reuse the pair slots");
   const int lane = tid & 63, wv = tid >> 6, grp = lane >> 4, p = lane & 15;
-  const int blk = (2 * (wv >> 1) + (grp >> 1)) * 4 + 2 * (wv & 1) + (grp & 1);  // block index in the tile, row-major 4x4
+  const int blk = 4 * wv + grp;  // block id = 4 * quadrant + row (the bit numbering of the forward's hit masks)
   const float tcx = tx0 + 8.f, tcy = ty0 + 8.f;
   const float lx = px - tcx, ly = py - tcy;
   const float lxx = lx * lx, lxy = lx * ly, lyy = ly * ly;
@@ -148,12 +148,14 @@ __device__ __forceinline__ void graster_bwd_body(
   const int nb = (int)((re - rs + GSL_GB - 1) / GSL_GB);
   // records of batch b + 1 are gathered into registers while batch b is walked
   int pg = 0;
+  unsigned ph = 0;
   float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = make_float4(0.f, 0.f, 0.f, -1.f), pr2 = pr0;
   auto gather = [&](int b) {
     long long bend = re - 1 - (long long)b * GSL_GB;
     int bsize = (int)min((long long)GSL_GB, bend + 1 - rs);
     if (tid < bsize) {
       pg = flatten_ids[bend - tid];
+      if (isect_hits) ph = isect_hits[bend - tid];
       load_record(Q0, Q1, Q2, Qh, pg, RGB && CG == D, pr0, pr1, pr2);
     }
   };
@@ -171,10 +173,14 @@ __device__ __forceinline__ void graster_bwd_body(
       sb.s1[tid] = pr1;
       if (RGB && CG == D) sb.s2[tid] = pr2;
     }
-    // which of the 16 blocks can the staged splat reach?  alpha >= 1/255 disc (radius r1.w) against the rectangle of
-    // the block's pixel centres, and nothing behind the block's last composited entry
+    // which of the 16 blocks walk the staged entry?  Exactly those that composited it on some pixel in the forward
+    // (isect_hits); without the forward's masks: alpha >= 1/255 disc (radius r1.w) against the rectangle of the
+    // block's pixel centres, and nothing behind the block's last composited entry.  Block q = 4 * quadrant + row sits
+    // at (2 (quadrant & 1) + (row & 1), 2 (quadrant >> 1) + (row >> 1)) of the 4x4 blocks of the tile.
     unsigned hits = 0;
-    if (staged && r1.w >= 0.f) {
+    if (isect_hits) {
+      hits = staged ? ph : 0u;
+    } else if (staged && r1.w >= 0.f) {
       const float rr = r1.w * r1.w;
       const int age = (int)(bend - tid);
       float ddx[4], ddy[4];
@@ -187,7 +193,8 @@ __device__ __forceinline__ void graster_bwd_body(
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        bool h = (ddx[q & 3] <= ddy[q >> 2]) && (age <= bfinal[q]);
+        const int bx = 2 * ((q >> 2) & 1) + (q & 1), by = 2 * (q >> 3) + ((q >> 1) & 1);
+        bool h = (ddx[bx] <= ddy[by]) && (age <= bfinal[q]);
         hits |= (h ? 1u : 0u) << q;
       }
     }
@@ -239,7 +246,7 @@ __device__ __forceinline__ void graster_bwd_body(
       int kw[4];
       for (int w = 0; w < 4; ++w) {
         kw[w] = 0;
-        for (int g2 = 0; g2 < 4; ++g2) kw[w] = max(kw[w], sb.btot[(2 * (w >> 1) + (g2 >> 1)) * 4 + 2 * (w & 1) + (g2 & 1)]);
+        for (int g2 = 0; g2 < 4; ++g2) kw[w] = max(kw[w], sb.btot[4 * w + g2]);
       }
       atomicAdd(&g16_stats[6], (unsigned long long)max(max(kw[0], kw[1]), max(kw[2], kw[3])));
       int tot = 0;
@@ -406,7 +413,8 @@ __global__ __launch_bounds__(256) void k_graster_bwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh) {
+    float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
+    const uint16_t* __restrict__ isect_hits) {
   __shared__ GStage<D, CG> sb;
   __shared__ int s_final[4];
   __shared__ int s_bfinal[16];  // per 4x4 block: last list index any of its pixels composited
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256) void k_graster_bwd(
   row_final = max(row_final, __shfl_xor(row_final, 2, 64));
   row_final = max(row_final, __shfl_xor(row_final, 4, 64));
   row_final = max(row_final, __shfl_xor(row_final, 8, 64));
-  int blk = (2 * (wv >> 1) + (grp >> 1)) * 4 + 2 * (wv & 1) + (grp & 1);
+  int blk = 4 * wv + grp;
   if (p == 0) s_bfinal[blk] = row_final;
   int wave_final = max(row_final, __shfl_xor(row_final, 16, 64));
   wave_final = max(wave_final, __shfl_xor(wave_final, 32, 64));
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256) void k_graster_bwd(
   if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
   if (rs >= re) return;
   graster_bwd_body<D, CG>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, tid, px, py, (float)(txi * 16), (float)(tyi * 16),
-                          inside, bin_final, T_final, vc, va, s_bfinal);
+                          inside, bin_final, T_final, vc, va, s_bfinal, isect_hits);
 }
 
 }  // namespace gsl
@@ -481,14 +489,14 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const int32_t* flatten_ids, int64_t capacity, const float* render,
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                         void* stream) {
+                                         const uint16_t* isect_hits, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
 #define CALL_G(DD, EE, CC)                                                                                   \
   hipLaunchKernelGGL((gsl::k_graster_bwd<DD, EE, CC>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,      \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,   \
-                     row0, row1, (const uint4*)Qh)
+                     row0, row1, (const uint4*)Qh, isect_hits)
   if (channels == 1) { if (ed) CALL_G(1, true, 1); else CALL_G(1, false, 1); }
   else if (channels == 3) { CALL_G(3, false, 3); }
   else if (channels == 4) {

@@ -32,6 +32,7 @@ struct PStage {
   float4 s2[(D >= 3) ? 256 : 1];
   uint16_t qlist[4][256];  // per-quadrant candidate slots, in list order
   int qcnt[4][4];          // [staging wave][quadrant]
+  uint8_t hit[4][256];     // [quadrant][batch slot]: which of the quadrant's four 4x4 blocks composited the entry
 };
 
 // Order-preserving compaction of the staged batch into per-quadrant candidate lists.
@@ -79,6 +80,10 @@ __device__ __forceinline__ void masked_mov2(unsigned& dlo, unsigned& dhi, unsign
                : "s"(vlo), "s"(vhi), "s"(lanes)
                : "scc");
 }
+// BLOCKROWS = false: lane = 8 y + x of the quadrant (k_tiny_bwd); true: each 16-lane DPP row is one 4x4 pixel block,
+// lane = 16 g + p with x = 4 (g & 1) + (p & 3), y = 4 (g >> 1) + (p >> 2) (k_praster_fwd: the compositing backward of
+// raster_g16.hip uses the same mapping, and a per-block OR of "who composited what" is then a row reduction).
+template <bool BLOCKROWS = false>
 __device__ __forceinline__ void pixel_masks(int lox, int hix, int loy, int hiy, int lane, unsigned& mlo, unsigned& mhi) {
   unsigned clo = 0, chi = 0, rlo = 0, rhi = 0;
   (void)lane;
@@ -86,11 +91,25 @@ __device__ __forceinline__ void pixel_masks(int lox, int hix, int loy, int hiy, 
   for (int v = 0; v < 8; ++v) {
     unsigned long long mc = __ballot(lox <= v && v <= hix);
     unsigned long long mr = __ballot(loy <= v && v <= hiy);
-    masked_mov2(clo, chi, mc, 0x0101010101010101ull << v);  // lanes of pixel column v
-    masked_mov2(rlo, rhi, mr, 0xFFull << (8 * v));          // lanes of pixel row v
+    if (BLOCKROWS) {
+      masked_mov2(clo, chi, mc, (0x0000111100001111ull << (v & 3)) << (16 * (v >> 2)));  // lanes of pixel column v
+      masked_mov2(rlo, rhi, mr, (0x00000000000F000Full << (4 * (v & 3))) << (32 * (v >> 2)));  // lanes of pixel row v
+    } else {
+      masked_mov2(clo, chi, mc, 0x0101010101010101ull << v);  // lanes of pixel column v
+      masked_mov2(rlo, rhi, mr, 0xFFull << (8 * v));          // lanes of pixel row v
+    }
   }
   mlo = clo & rlo;
   mhi = chi & rhi;
+}
+
+// OR over the 16 lanes of a DPP row (every lane of the row gets the result).
+__device__ __forceinline__ unsigned row_or(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+  return v;
 }
 
 __device__ __forceinline__ void box_range(float centre_rel, float r, int& lo, int& hi) {
@@ -105,7 +124,8 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-    int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts) {
+    int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
+    uint16_t* __restrict__ isect_hits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ PStage<D> sb;
@@ -116,7 +136,9 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  int j = qx + (lane & 7), i = qy + (lane >> 3);
+  // DPP row g = 4x4 block g of the quadrant; lane p of the row = pixel (p & 3, p >> 2) of the block
+  int grp = lane >> 4, pp = lane & 15;
+  int j = qx + 4 * (grp & 1) + (pp & 3), i = qy + 4 * (grp >> 1) + (pp >> 2);
   float px = (float)j + 0.5f, py = (float)i + 0.5f;
   bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
   bool done = !inside;
@@ -132,8 +154,22 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
 #pragma unroll
   for (int k = 0; k < D; ++k) pix[k] = 0.f;
 
+  // isect_hits (may be NULL): per list entry, which of the tile's 16 blocks composited it on at least one pixel
+  // (bit 4 * quadrant + row): the compositing backward walks exactly those (block, entry) pairs
+  auto flush_hits = [&](int b) {  // after a barrier: every wave has finished batch b
+    long long bstart = rs + (long long)b * 256;
+    if (bstart + tid < re) {
+      unsigned h = (unsigned)sb.hit[0][tid] | ((unsigned)sb.hit[1][tid] << 4) | ((unsigned)sb.hit[2][tid] << 8) |
+                   ((unsigned)sb.hit[3][tid] << 12);
+      isect_hits[bstart + tid] = (uint16_t)h;
+    }
+  };
+  int b_done = -1;  // last batch whose hits are still in LDS
   for (int b = 0; b < nb; ++b) {
-    if (__syncthreads_and(done)) break;
+    int all_done = __syncthreads_and(done);
+    if (isect_hits && b_done >= 0) flush_hits(b_done);
+    b_done = -1;
+    if (all_done) break;
     long long bstart = rs + (long long)b * 256;
     int bsize = (int)min((long long)256, re - bstart);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
@@ -145,7 +181,12 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
       sb.s1[tid] = r1;
       if (RGB) sb.s2[tid] = r2;
     }
+    if (isect_hits) {  // (the barrier inside compact_quadrants orders this after flush_hits' reads)
+      __syncthreads();
+      reinterpret_cast<unsigned*>(&sb.hit[0][0])[tid] = 0u;
+    }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
+    b_done = b;
     for (int c = 0; c < n; c += 64) {
       if (__all(done)) break;
       int e = c + lane;
@@ -158,8 +199,9 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
         box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
       }
       unsigned mlo, mhi;
-      pixel_masks(lox, hix, loy, hiy, lane, mlo, mhi);
+      pixel_masks<true>(lox, hix, loy, hiy, lane, mlo, mhi);
       if (done) { mlo = 0; mhi = 0; }
+      unsigned cm[2] = {0u, 0u};  // candidates of this chunk this pixel composited
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         unsigned m = half ? mhi : mlo;
@@ -194,6 +236,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
                 if (DEPTH) pix[D - 1] += p0.z * vis;
                 cur_idx = (int)bstart + t0;
                 T = nT;
+                cm[half] |= 1u << bit0;
               }
             }
             if (two && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN) {
@@ -209,12 +252,31 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
                 if (DEPTH) pix[D - 1] += u0.z * vis;
                 cur_idx = (int)bstart + t1;
                 T = nT;
+                cm[half] |= 1u << bit1;
               }
             }
           }
         }
       }
+      if (isect_hits) {
+        // per DPP row (= 4x4 block): OR of the pixels' composited-candidate masks; lane e then owns candidate c + e
+        // and collects its bit from the four rows
+        unsigned rlo = row_or(cm[0]), rhi = row_or(cm[1]);
+        unsigned nib = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          unsigned glo = (unsigned)__builtin_amdgcn_readlane((int)rlo, 16 * g);
+          unsigned ghi = (unsigned)__builtin_amdgcn_readlane((int)rhi, 16 * g);
+          unsigned long long gm = ((unsigned long long)ghi << 32) | glo;
+          nib |= (unsigned)((gm >> lane) & 1ull) << g;
+        }
+        if (nib) sb.hit[wv][sb.qlist[wv][e < n ? e : 0]] = (uint8_t)nib;  // (a set bit implies e < n)
+      }
     }
+  }
+  if (isect_hits && b_done >= 0) {
+    __syncthreads();
+    flush_hits(b_done);
   }
   if (inside) {
     size_t pid = (size_t)i * W + j;
@@ -419,7 +481,8 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
 extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
-                                 int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws, void* stream) {
+                                 int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws,
+                                 uint16_t* isect_hits, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -435,7 +498,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
-                     (int32_t*)binned_ws)
+                     (int32_t*)binned_ws, isect_hits)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();

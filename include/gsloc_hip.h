@@ -154,8 +154,13 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  * gsl_fused_raster_fwd / _bwd : compositing and its vjp; the vjp ACCUMULATES into vacc, 16 floats
  *                     per Gaussian ([v_xy 2][v_conic 3][v_opacity 1][v_colour channels]), zero on entry.
  *                     Forward: every lane walks the candidate list of its own pixel (csrc/raster_px.hip);
- *                     backward: quadrant walk, per-splat pixel sums on the matrix cores
- *                     (v_mfma_f32_16x16x4_f32, exact f32; csrc/fused.hip).  Only pixel rows [row0,row1)
+ *                     backward: each 16-lane DPP row of a wave walks the list of its own 4x4 pixel block
+ *                     (csrc/raster_g16.hip; deterministic mode: quadrant walk with per-splat pixel sums on the
+ *                     matrix cores, v_mfma_f32_16x16x4_f32, exact f32, csrc/fused.hip).  isect_hits (uint16 per
+ *                     intersection, may be NULL in both calls): the forward records for every list entry which of
+ *                     the tile's 16 blocks composited it on at least one pixel (bit 4 * quadrant + row), and the
+ *                     backward given the same array walks exactly those (block, entry) pairs instead of testing the
+ *                     splat's alpha >= 1/255 disc against the blocks.  Only pixel rows [row0,row1)
  *                     of the tile rows [ty0,ty1) are rendered / back-propagated (whole strip: 0,height):
  *                     a strip's one-pixel Sobel halo costs one pixel row, not a tile row.
  * fp16 staging (Qh, may be NULL everywhere): gsl_fused_project additionally packs one 32-byte record per Gaussian
@@ -209,13 +214,13 @@ int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int 
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
-                         void* binned_ws, void* stream);
+                         void* binned_ws, uint16_t* isect_hits, void* stream);
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                         const void* Qh, float* vrow, void* stream);
+                         const void* Qh, float* vrow, const uint16_t* isect_hits, void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,
