@@ -94,6 +94,7 @@ class RenderContext:
         # device-set, sticky: [0] a splat outgrew the tiny backward, [1] a tile outgrew its bin, [2] that tile's size
         self.flags = torch.zeros(4, dtype=i32, device=dev)
         self.bins, self.bin_cap = None, 0
+        self._counters_dirty = False
         self.trec = self.vcT = None
         self.keys = self.flatten_ids = self.hits = None
         if capacity is not None:
@@ -132,6 +133,13 @@ class RenderContext:
         self.bin_cap = int(bin_cap)
         self.bins = torch.zeros(self.n_tiles * self.bin_cap, dtype=torch.int64, device=self.device)
         self.ws.zero_()  # the binned projection relies on cleared tile counters (it leaves them cleared)
+        self.flags[3] = 0
+        self._counters_dirty = False
+
+    def counters_were_dirty(self) -> bool:
+        """Host sync: did a binned projection start on tile counters a skipped / failed forward had left uncleared?
+        (flags[3], raised by the projection kernel; the lists of that iteration are then wrong.)"""
+        return bool(self.bins is not None and int(self.flags[3].item()))
 
     def bins_overflowed(self) -> int:
         """Host sync: 0, or the length of the longest tile list that did not fit its bin since the last calibration."""
@@ -179,10 +187,17 @@ class RenderContext:
             raise RuntimeError("a splat outgrew the tiny-splat backward (r_cull >= 2 px); call calibrate() again")
         if self.bins_overflowed():
             raise RuntimeError(f"a tile list outgrew its bin ({self.bins_overflowed()} > {self.bin_cap}); call calibrate() again")
+        if self.counters_were_dirty():
+            raise RuntimeError("a binned projection found the tile counters uncleared (a forward was skipped between two "
+                               "projections); call calibrate() again")
         return n
 
     # ------------------------------------------------------------------ stages (one C-ABI call each)
     def _project(self, means, quats, scales, opacities, colors, viewmat, K) -> None:
+        if self.bins is not None:
+            if self._counters_dirty:  # the previous projection was never followed by a compositing forward
+                self.ws.zero_()
+            self._counters_dirty = True
         check(self.lib.gsl_fused_project(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, self.near, self.far,
@@ -206,6 +221,7 @@ class RenderContext:
                                             ptr(self.ws) if self.bins is not None else None, ptr(self.hits),
                                             current_stream()),
               "gsl_fused_raster_fwd")
+        self._counters_dirty = False
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,

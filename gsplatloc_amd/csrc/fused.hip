@@ -53,9 +53,16 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     float far_plane, float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
     int32_t* __restrict__ radii, float4* __restrict__ Q0, float4* __restrict__ Q1, float4* __restrict__ Q2,
     float* __restrict__ comps, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts,
-    uint4* __restrict__ Qh, uint64_t* __restrict__ bins, int bin_cap) {
+    uint4* __restrict__ Qh, uint64_t* __restrict__ bins, int bin_cap, int32_t* __restrict__ bin_state,
+    int32_t* __restrict__ flags) {
   extern __shared__ int s_hist[];
   int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
+  // Counter contract of the binned mode: the tile counters must be zero on entry -- the compositing forward of the
+  // previous iteration clears them and marks the state word clean.  A projection that finds the state dirty (a forward
+  // was skipped or failed between two projections) raises flags[3] instead of binning on top of stale sizes silently.
+  if (BINNED && bin_state && nst > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (atomicExch(bin_state, 1) != 0 && flags) flags[3] = 1;
+  }
   for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) s_hist[k] = 0;
   __syncthreads();
   int i = blockIdx.x * GSL_F_BIN_THREADS + threadIdx.x;
@@ -894,7 +901,8 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
   hipLaunchKernelGGL((gsl::k_fproject<RGBV, BINV>), grid, block, lds, st, means, quats, scales, opacities, colors,    \
                      sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,        \
                      antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,             \
-                     compensations, tiles_per_gauss, counts, (uint4*)Qh, (uint64_t*)bins, bin_cap)
+                     compensations, tiles_per_gauss, counts, (uint4*)Qh, (uint64_t*)bins, bin_cap,                   \
+                     bins ? cursors : (int32_t*)nullptr, flags)
     if (Q2) { if (bins) CALL_P(true, true); else CALL_P(true, false); }
     else { if (bins) CALL_P(false, true); else CALL_P(false, false); }
 #undef CALL_P

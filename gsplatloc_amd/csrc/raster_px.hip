@@ -125,14 +125,17 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
     int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
-    uint16_t* __restrict__ isect_hits) {
+    int32_t* __restrict__ clear_state, uint16_t* __restrict__ isect_hits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ PStage<D> sb;
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
   // projection (no clearing launch; sizes of tiles outside the strip are never raised)
-  if (clear_counts && threadIdx.x == 0) clear_counts[tile] = 0;
+  if (clear_counts && threadIdx.x == 0) {
+    clear_counts[tile] = 0;
+    if (blockIdx.x == 0 && clear_state) *clear_state = 0;  // counters consumed and cleared: the next projection may bin
+  }
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
@@ -498,7 +501,8 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
-                     (int32_t*)binned_ws, isect_hits)
+                     (int32_t*)binned_ws, binned_ws ? (int32_t*)binned_ws + tile_w * tile_h : (int32_t*)nullptr,   \
+                     isect_hits)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();

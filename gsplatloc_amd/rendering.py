@@ -104,7 +104,8 @@ def rasterization(
         return render[None], alphas[None], meta
 
     # General path (several cameras, a background colour): the stage operators, one after the other.
-    # ``channel_chunk`` is accepted for signature compatibility; the compositing operator takes any channel count.
+    # Features wider than ``channel_chunk`` (gsplat's default 32, the widest compositing kernel here) are composited in
+    # chunks of that many channels, as gsplat does; every chunk yields the same alphas, the first one's are returned.
     want_depth = render_mode in ("D", "ED", "RGB+D", "RGB+ED")
     want_rgb = render_mode.startswith("RGB")
     radii, means2d, depths, conics, compensations = fully_fused_projection(
@@ -139,8 +140,20 @@ def rasterization(
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height,
                                                           packed=False, n_cameras=C)
     isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
-    render_colors, render_alphas = rasterize_to_pixels(means2d, conics, feats, opac, width, height, tile_size,
-                                                       isect_offsets, flatten_ids, backgrounds=bg)
+    chunk = min(int(channel_chunk), 32)
+    assert chunk >= 1, channel_chunk
+    if feats.shape[-1] > chunk:
+        parts, render_alphas = [], None
+        for lo in range(0, feats.shape[-1], chunk):
+            part, part_alphas = rasterize_to_pixels(means2d, conics, feats[..., lo:lo + chunk].contiguous(), opac, width,
+                                                    height, tile_size, isect_offsets, flatten_ids,
+                                                    backgrounds=None if bg is None else bg[..., lo:lo + chunk].contiguous())
+            parts.append(part)
+            render_alphas = part_alphas if render_alphas is None else render_alphas
+        render_colors = torch.cat(parts, dim=-1)
+    else:
+        render_colors, render_alphas = rasterize_to_pixels(means2d, conics, feats, opac, width, height, tile_size,
+                                                           isect_offsets, flatten_ids, backgrounds=bg)
     if render_mode in ("ED", "RGB+ED"):  # expected depth: accumulated depth over accumulated alpha
         expected = render_colors[..., -1:] / render_alphas.clamp(min=1e-10)
         render_colors = torch.cat([render_colors[..., :-1], expected], dim=-1)

@@ -186,7 +186,11 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     its second read of the records, the scan launch and the counter-clearing launch disappear.
  *                     ws must be zero-filled once before the first call.  A tile that outgrows bin_cap keeps its
  *                     first bin_cap entries, raises flags[1] = 1 and leaves the largest count in flags[2]
- *                     (flags: 4 ints, may be NULL): poll it and re-run with larger bins.
+ *                     (flags: 4 ints, may be NULL): poll it and re-run with larger bins.  Counter contract: the
+ *                     counters in ws must be zero when gsl_fused_project starts; gsl_fused_raster_fwd(binned_ws = ws)
+ *                     leaves them so.  A projection that follows another one without a compositing forward in
+ *                     between (skipped, or failed) finds the state word in ws dirty and raises flags[3] = 1: zero-fill
+ *                     ws and run the iteration again.
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
  *                     v_viewmat[16] is overwritten (row 3 = 0).  tiny_trec / tiny_vcT (may be NULL): the slabs

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.parity import POSE_GRAD_TOL, agreeing_pixels, rel_inf, report
+from tests.parity import FLOOR32_MAX, POSE_GRAD_TOL, agreeing_pixels, pose_grad_bound, rel_inf, report
 
 pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 1, 16)
@@ -47,24 +47,35 @@ def _context_vs_c_oracle(tag, sc, V, W, H, v, max_flipped, grad_names=("means", 
     valid = depth_o > 0
     depth_rel = float(((depth_g - depth_o).abs()[valid] / depth_o[valid]).max())
     alpha_abs = float((alphas[..., 0].cpu().double()[ok] - torch.from_numpy(want_f["alphas"])[ok]).abs().max())
-    vm = v * ok[..., None]
-    want = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f64",
-                           threads=THREADS)
-    grads = ctx.backward(vm.float().to(dev).contiguous(), torch.zeros(H, W, 1, device=dev), full=True)
-    torch.cuda.synchronize()
-    ctx.check_capacity()
-    pose_err = rel_inf(grads["viewmat"][:3], want["v_viewmat"][:3])
-    # the float32 floor of this configuration: the oracle's own float32 build against its float64 build
-    want32 = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f32",
-                             threads=THREADS)
-    floor32 = rel_inf(want32["v_viewmat"][:3], want["v_viewmat"][:3])
+    # pose gradient for SEVERAL upstream gradients (white noise on the depth channel, seeds 1..3 by default): the number
+    # moves with the noise realisation, so one draw is not a parity statement.  Per seed: HIP against the
+    # float64 oracle, HIP against the oracle's float32 build (like for like), and the float32 floor of the
+    # configuration (the oracle's float32 build against its float64 build).
+    upstreams = v if isinstance(v, (list, tuple)) else [v]
+    pose_err = hip_vs_f32 = floor32 = 0.0
+    grads = want = None
+    for vk in upstreams:
+        vm = vk * ok[..., None]
+        want = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f64",
+                               threads=THREADS)
+        ctx.forward(*inp)
+        grads = ctx.backward(vm.float().to(dev).contiguous(), torch.zeros(H, W, 1, device=dev), full=True)
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        want32 = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f32",
+                                 threads=THREADS)
+        pose_err = max(pose_err, rel_inf(grads["viewmat"][:3], want["v_viewmat"][:3]))
+        hip_vs_f32 = max(hip_vs_f32, rel_inf(grads["viewmat"][:3], want32["v_viewmat"][:3]))
+        floor32 = max(floor32, rel_inf(want32["v_viewmat"][:3], want["v_viewmat"][:3]))
     errs = dict(render_rel_median=float(qs[0]), render_rel_p99=float(qs[1]), depth_rel=depth_rel, alpha_abs=alpha_abs,
-                v_viewmat=pose_err, v_viewmat_f32_oracle=floor32)
-    for name in grad_names:
+                v_viewmat=pose_err, v_viewmat_vs_f32_oracle=hip_vs_f32, v_viewmat_f32_oracle_vs_f64=floor32,
+                upstream_seeds=float(len(upstreams)))
+    for name in grad_names:  # (of the last upstream)
         a, b = grads[name].cpu().double().numpy().reshape(-1), want["v_" + name].reshape(-1)
         errs["v_" + name] = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     report(tag, flipped, **errs)
-    assert pose_err < max(POSE_GRAD_TOL, 2.0 * floor32), f"{tag}: pose gradient {pose_err:.2e} (float32 floor {floor32:.2e})"
+    assert floor32 < FLOOR32_MAX, f"{tag}: the float32 floor itself is {floor32:.2e}"
+    assert pose_err < pose_grad_bound(floor32), f"{tag}: pose gradient {pose_err:.2e} (float32 floor {floor32:.2e})"
     for name in grad_names:  # relative L2 over all Gaussians; a splat whose own alpha sits on 1/255 at a nearly opaque
         assert errs["v_" + name] < 5e-3, (tag, name, errs["v_" + name])  # pixel switches without moving the pixel
     return errs
@@ -88,7 +99,7 @@ def test_config_R_and_X_render_and_gradients_match_the_c_oracle(N, W, H, sigma_p
     sc = random_scene(N, W, H, sigma_px=sigma_px, order=order)
     V = torch.linalg.inv(perturbed_pose())
     _context_vs_c_oracle(f"{'X' if N > 1_000_000 else 'R'} N={N} {W}x{H} sigma={sigma_px} {order}", sc, V, W, H,
-                         _depth_upstream(H, W), max_flipped)
+                         [_depth_upstream(H, W, seed=k) for k in (1, 2, 3)], max_flipped)
 
 
 def _tum_like_frame(W=640, H=480, hole_frac=0.08, seed=3):
@@ -123,7 +134,8 @@ def test_config_T_depth_frame_with_invalid_pixels():
     W, H = 640, 480
     assert sc["means"].shape[0] == W * H and n_valid < W * H
     V = torch.linalg.inv(fp["c2w1"])
-    _context_vs_c_oracle(f"T N={W * H} ({n_valid} valid) {W}x{H}", sc, V, W, H, _depth_upstream(H, W, seed=5), 5e-3)
+    _context_vs_c_oracle(f"T N={W * H} ({n_valid} valid) {W}x{H}", sc, V, W, H,
+                         [_depth_upstream(H, W, seed=k) for k in (5, 6, 7)], 5e-3)
 
 
 def test_config_S_tracker_200_iterations():
@@ -256,8 +268,11 @@ def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
         grad[precision] = Vo.grad[:3].clone()
     err, floor32 = rel_inf(got[:3], grad["f64"]), rel_inf(grad["f32"], grad["f64"])
     report(f"tracker-loss pose gradient, {N} Gaussians 640x480", 0.0,
-           loss_rel=abs(loss_g - float(total["f64"])) / float(total["f64"]), v_viewmat=err, v_viewmat_f32_oracle=floor32)
+           loss_rel=abs(loss_g - float(total["f64"])) / float(total["f64"]), v_viewmat=err,
+           v_viewmat_vs_f32_oracle=rel_inf(got[:3], grad["f32"]), v_viewmat_f32_oracle_vs_f64=floor32)
     assert abs(loss_g - float(total["f64"])) < 1e-4 * float(total["f64"])
     # an L1 loss has sign(d - g) in its gradient: where the rendered and the target depth cross, float32 rounding of d
-    # flips the sign of that pixel's term, so the gradient carries a float32 floor well above the loss's own
-    assert err < max(POSE_GRAD_TOL, 2.0 * floor32), (err, floor32)
+    # flips the sign of that pixel's term, so the gradient carries a float32 floor well above the loss's own.  The
+    # bound follows the measured floor but is capped, and the floor itself is bounded (tests/parity.py).
+    assert floor32 < FLOOR32_MAX, floor32
+    assert err < max(POSE_GRAD_TOL, min(2.0 * floor32, 1e-3)), (err, floor32)
