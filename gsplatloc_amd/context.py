@@ -69,7 +69,11 @@ class RenderContext:
         self.vrow = None
         self.comps = torch.zeros(N, dtype=f32, device=dev) if self.antialiased else None
         self.offs = torch.zeros(self.n_tiles + 1, dtype=i32, device=dev)
-        self.n_is = torch.zeros(1, dtype=i32, device=dev)
+        # [flags 0..3 | n_isects]: one buffer, so that a caller that must look at them reads them with ONE copy.
+        # flags (device-set, sticky): [0] a splat outgrew the tiny backward, [1] a tile outgrew its bin, [2] that tile's
+        # size, [3] a binned projection started on uncleared tile counters
+        self.status = torch.zeros(8, dtype=i32, device=dev)
+        self.n_is = self.status[4:5]
         self.ws_bytes = self.lib.gsl_fused_ws_bytes(N, self.n_tiles)
         self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.render = torch.zeros(self.H, self.W, self.D, dtype=f32, device=dev)
@@ -91,8 +95,10 @@ class RenderContext:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
         self.capacity = 0
         self.tiny = False
-        # device-set, sticky: [0] a splat outgrew the tiny backward, [1] a tile outgrew its bin, [2] that tile's size
-        self.flags = torch.zeros(4, dtype=i32, device=dev)
+        self.flags = self.status[0:4]
+        self.last_n_isects = 0
+        self.tiles_per_gauss = None  # optional [N] int32 output of the projection (gsplat's meta key)
+        self.generation = 0  # counts forwards: an autograd node checks that "its" forward is still the last one
         self.bins, self.bin_cap = None, 0
         self._counters_dirty = False
         self.trec = self.vcT = None
@@ -156,7 +162,8 @@ class RenderContext:
         more than 4x4 pixel centres (r_cull < 2 px) -- GsplatLoc's as-coded scales; otherwise the general
         compositing backward.  GSLOC_BWD=general disables it (dev switch)."""
         r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
-        want = os.environ.get("GSLOC_BWD", "auto") != "general" and r_max < TINY_RCULL_MAX and self.Qh is None
+        want = (os.environ.get("GSLOC_BWD", "auto") != "general" and r_max < TINY_RCULL_MAX and self.Qh is None
+                and getattr(self, "allow_tiny", True))
         if want and self.trec is None:
             self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
             self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
@@ -202,7 +209,8 @@ class RenderContext:
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, self.near, self.far,
             self.radius_clip, int(self.antialiased), self.tw, self.th, self.ty0, self.ty1, ptr(self.radii),
-            ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), ptr(self.comps), None, ptr(self.offs), ptr(self.n_is),
+            ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), ptr(self.comps), ptr(self.tiles_per_gauss), ptr(self.offs),
+            ptr(self.n_is),
             ptr(self.ws), self.ws_bytes, ptr(self.Qh), ptr(self.bins), self.bin_cap, ptr(self.flags),
             current_stream()), "gsl_fused_project")
 
@@ -264,7 +272,37 @@ class RenderContext:
         self._bin()
         self._raster_fwd()
         self._inputs = (means, quats, scales, opacities, colors, viewmat, K)
+        self.generation += 1
         return self.render, self.alphas
+
+    def forward_checked(self, means, quats, scales, opacities, colors, viewmat, K) -> Optional[str]:
+        """forward() with the overflow check placed where gsplat has its own synchronisation: after projection and
+        binning (cheap kernels), before compositing.  Returns None and the rendered buffers are valid, or the reason
+        the lists are incomplete (compositing skipped: grow the buffers / calibrate() and call again)."""
+        assert self.keys is not None, "call calibrate() (or pass capacity=) before forward()"
+        self._project(means, quats, scales, opacities, colors, viewmat, K)
+        self._bin()
+        why = self.overflow_status()
+        if why is not None:
+            return why  # (the tile counters stay uncleared: _project / calibrate() zero them before the next use)
+        self._raster_fwd()
+        self._inputs = (means, quats, scales, opacities, colors, viewmat, K)
+        self.generation += 1
+        return None
+
+    def overflow_status(self) -> Optional[str]:
+        """Host sync (one 32-byte copy): None, or why the last forward's lists are incomplete."""
+        st = self.status.tolist()
+        self.last_n_isects = min(int(st[4]), self.capacity)
+        if st[4] > self.capacity:
+            return f"intersection capacity exceeded ({st[4]} > {self.capacity})"
+        if self.bins is not None and st[1]:
+            return f"a tile list outgrew its bin ({st[2]} > {self.bin_cap})"
+        if self.bins is not None and st[3]:
+            return "tile counters were not cleared"
+        if self.tiny and st[0]:
+            return "a splat outgrew the tiny-splat backward"
+        return None
 
     def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None,
                  reduce_viewmat: bool = True) -> Dict[str, Tensor]:

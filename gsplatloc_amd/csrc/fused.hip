@@ -858,6 +858,10 @@ __global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict
 // ws = [tile_counts n_tiles][cursors n_tiles][pad to 16 bytes][pose-gradient rows ceil(N/256) x 16 floats]
 static inline size_t gsl_vm_rows_offset(int n_tiles) { return ((size_t)2 * (size_t)n_tiles * sizeof(int32_t) + 15) & ~(size_t)15; }
 
+// state word of the binned mode's counter contract: the 16th float of the first pose-gradient row (rows use 15)
+static inline int32_t* gsl_bin_state(void* ws, int n_tiles) { return (int32_t*)((char*)ws + gsl_vm_rows_offset(n_tiles)) + 15; }
+extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles) { return (ws && n_tiles > 0) ? gsl_bin_state(ws, n_tiles) : nullptr; }
+
 extern "C" size_t gsl_fused_ws_bytes(int N, int n_tiles) {
   // [tile_counts n_tiles][cursors n_tiles][partials ceil(N/256)*16 floats]
   size_t nb = ((size_t)(N > 0 ? N : 1) + 255) / 256;
@@ -902,7 +906,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
                      sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,        \
                      antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,             \
                      compensations, tiles_per_gauss, counts, (uint4*)Qh, (uint64_t*)bins, bin_cap,                   \
-                     bins ? cursors : (int32_t*)nullptr, flags)
+                     bins ? gsl_bin_state(ws, n_tiles) : (int32_t*)nullptr, flags)
     if (Q2) { if (bins) CALL_P(true, true); else CALL_P(true, false); }
     else { if (bins) CALL_P(false, true); else CALL_P(false, false); }
 #undef CALL_P

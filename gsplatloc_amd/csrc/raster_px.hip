@@ -474,6 +474,8 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
   return GSL_OK;
 }
 
+extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles);  // fused.hip: the state word inside ws
+
 #define GSL_P_DISPATCH(D, ED, CALL)                                \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }      \
   else if (D == 3) { CALL(3, false); }                             \
@@ -501,8 +503,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
-                     (int32_t*)binned_ws, binned_ws ? (int32_t*)binned_ws + tile_w * tile_h : (int32_t*)nullptr,   \
-                     isect_hits)
+                     (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();

@@ -138,6 +138,136 @@ class _FusedRasterization(torch.autograd.Function):
                 v_opac if ni[3] else None, v_colors if (ni[4] and rgb) else None, v_viewmat, None, None, None)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Drop-in call with a cached RenderContext.  `from gsplat import rasterization` under the reference's loop
+# (/root/reference/src/my_gsplat/gs_trainer_total.py:79-267) renders the same N Gaussians at the same size a few hundred
+# times per frame: allocating ~15 tensors per call, binning in two passes and reading the intersection count back to
+# size them (what gsplat itself does, and what _FusedRasterization above does) made that call allocator- and
+# launch-bound (0.43 ms wall for 0.09 ms of kernels at S).  Here the context -- records, bins,
+# lists, capacity -- is kept per call signature; a call is 3 launches into freshly allocated OUTPUT tensors (the caller
+# owns what it gets; nothing returned aliases the context), one 32-byte status read (overflow flags and count: the
+# lists are complete or the call is repeated after growing the buffers), and the backward is 3 launches.
+# GSLOC_DROPIN_CACHE=0 selects the allocate-per-call path.
+_CTX_CACHE: Dict[tuple, "object"] = {}
+_CTX_CACHE_MAX = 4
+
+
+def _cached_context(key, make):
+    rc = _CTX_CACHE.pop(key, None)
+    if rc is None:
+        rc = make()
+        while len(_CTX_CACHE) >= _CTX_CACHE_MAX:
+            _CTX_CACHE.pop(next(iter(_CTX_CACHE)))
+    _CTX_CACHE[key] = rc  # most recently used last
+    return rc
+
+
+def clear_context_cache() -> None:
+    _CTX_CACHE.clear()
+
+
+class _CachedRasterization(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmat, K, rc, meta):
+        dev = means.device
+        f32, i32 = torch.float32, torch.int32
+        inputs = (means, quats, scales, opacities, colors if rc.rgb else None, viewmat, K)
+        if rc.keys is None:
+            rc.calibrate(*inputs)
+        for attempt in range(3):
+            # outputs are fresh tensors the caller owns; the kernels write every pixel of the frame
+            rc.render = torch.empty(rc.H, rc.W, rc.D, dtype=f32, device=dev)
+            rc.alphas = torch.empty(rc.H, rc.W, 1, dtype=f32, device=dev)
+            rc.last_ids = torch.empty(rc.H, rc.W, dtype=i32, device=dev)
+            why = rc.forward_checked(*inputs)
+            if why is None:
+                break
+            rc.calibrate(*inputs, headroom=1.5 * (attempt + 1))  # the scene moved past the head-room: re-measure, repeat
+        else:
+            raise RuntimeError(f"rasterization: buffers kept overflowing ({why})")
+        ctx.rc, ctx.gen = rc, rc.generation
+        ctx.save_for_backward(means, quats, scales, opacities, colors if rc.rgb else torch.empty(0, device=dev), viewmat, K,
+                              rc.render, rc.alphas, rc.last_ids)
+        if meta is not None:
+            meta.update(radii=rc.radii, Q0=rc.Q0, Q1=rc.Q1, offs=rc.offs, flatten_ids=rc.flatten_ids[:rc.last_n_isects],
+                        n_isects=rc.last_n_isects, last_ids=rc.last_ids, tiles_per_gauss=rc.tiles_per_gauss)
+        ctx.mark_non_differentiable(rc.last_ids)
+        return rc.render, rc.alphas, rc.last_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, _v_last):
+        rc = ctx.rc
+        means, quats, scales, opacities, colors, viewmat, K, render, alphas, last_ids = ctx.saved_tensors
+        dev = means.device
+        f32 = torch.float32
+        inputs = (means, quats, scales, opacities, colors if rc.rgb else None, viewmat, K)
+        rc.render, rc.alphas, rc.last_ids = render, alphas, last_ids
+        if rc.generation != ctx.gen:
+            # another forward has used this context since: its records and lists are not this node's any more --
+            # run this node's forward again (same inputs: same outputs, rewritten into the saved tensors)
+            rc.forward(*inputs)
+        rc._inputs = inputs
+        ni = ctx.needs_input_grad
+        full = any(ni[:5])
+        N = rc.N
+        if full:  # gradient tensors are fresh too
+            rc.v_means = torch.empty(N, 3, dtype=f32, device=dev)
+            rc.v_quats = torch.empty(N, 4, dtype=f32, device=dev)
+            rc.v_scales = torch.empty(N, 3, dtype=f32, device=dev)
+            rc.v_opacities = torch.empty(N, dtype=f32, device=dev)
+            rc.v_colors = torch.empty_like(colors) if rc.rgb else None
+        rc.v_viewmat = torch.empty(4, 4, dtype=f32, device=dev)
+        g = rc.backward(v_render.contiguous(), v_alphas.contiguous(), full=full)
+        return (g["means"] if ni[0] else None, g["quats"] if ni[1] else None, g["scales"] if ni[2] else None,
+                g["opacities"] if ni[3] else None, g["colors"] if (ni[4] and rc.rgb) else None,
+                g["viewmat"] if ni[5] else None, None, None, None)
+
+
+def cached_rasterization(means, quats, scales, opacities, colors, viewmat, K, width, height, sh_degree=None,
+                         render_mode="RGB", eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0,
+                         antialiased=False) -> Tuple[Tensor, Tensor, Dict]:
+    """fused_rasterization through a cached RenderContext (whole frame, one camera).  Same returns; the meta tensors
+    (radii, means2d, depths, conics, opacities, tile lists) are VIEWS of the context's buffers: valid until the next
+    call with the same signature (GsplatLoc never reads them); isect_ids is not produced."""
+    from .context import RenderContext
+
+    def prep(t, name):
+        assert t.is_cuda, f"{name} must live on the GPU (got {t.device}); there is no CPU path"
+        assert t.dtype == torch.float32, f"{name} must be float32 (got {t.dtype})"
+        return t.contiguous()
+
+    N = means.shape[0]
+    D, _ = _MODES[render_mode]
+    rgb = D >= 3
+    deg = -1 if sh_degree is None else int(sh_degree)
+    K_sh = colors.shape[1] if (rgb and deg >= 0) else 0
+    key = (N, int(width), int(height), render_mode, deg, K_sh, float(eps2d), float(near_plane), float(far_plane),
+           float(radius_clip), bool(antialiased), means.device.index)
+    rc = _cached_context(key, lambda: RenderContext(
+        N, width, height, render_mode, sh_degree=sh_degree, K_sh=K_sh, device=means.device, eps2d=eps2d,
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, antialiased=antialiased, full_grads=False))
+    rc.allow_tiny = False  # a splat that outgrew the tiny backward is only known after the backward: not in this API
+    rc.full_grads = True  # gradient buffers are allocated per call (owned by the caller), not by the context
+    if rc.tiles_per_gauss is None:
+        rc.tiles_per_gauss = torch.zeros(N, dtype=torch.int32, device=means.device)
+    raw: Dict = {}
+    render, alphas, _ = _CachedRasterization.apply(
+        prep(means, "means"), prep(quats, "quats"), prep(scales, "scales"), prep(opacities, "opacities"),
+        prep(colors, "colors") if rgb else colors, prep(viewmat, "viewmats"), prep(K, "Ks"), rc, raw)
+    tw, th = rc.tw, rc.th
+    Q0, Q1 = raw["Q0"], raw["Q1"]
+    meta = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": raw["radii"][None], "means2d": Q0[None, :, 0:2], "depths": Q0[None, :, 2],
+        "conics": Q1[None, :, 0:3], "opacities": Q0[None, :, 3],
+        "tile_width": tw, "tile_height": th, "tiles_per_gauss": raw["tiles_per_gauss"][None],
+        "isect_ids": None, "flatten_ids": raw["flatten_ids"],
+        "isect_offsets": raw["offs"][:-1].reshape(1, th, tw), "width": width, "height": height,
+        "tile_size": 16, "n_cameras": 1,
+    }
+    return render, alphas, meta
+
+
 def fused_supported(N: int, C: int, colors: Tensor, sh_degree: Optional[int], width: int, height: int,
                     tile_size: int, backgrounds, render_mode: str, tile_rows=None) -> bool:
     if C != 1 or tile_size != 16 or backgrounds is not None:

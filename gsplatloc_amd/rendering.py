@@ -17,7 +17,7 @@ from typing_extensions import Literal
 
 import os
 
-from .fused import fused_rasterization, fused_supported
+from .fused import cached_rasterization, fused_rasterization, fused_supported
 from .ops import (
     fully_fused_projection,
     isect_offset_encode,
@@ -97,7 +97,9 @@ def rasterization(
     # Hot path: one camera, no background -> the fused five-launch pipeline (csrc/fused.hip).
     if os.environ.get("GSLOC_DISABLE_FUSED", "0") != "1" and fused_supported(
             N, C, colors, sh_degree, width, height, tile_size, backgrounds, render_mode):
-        render, alphas, meta = fused_rasterization(
+        # the same call signature again and again (a tracker's loop): keep the context, see fused.py
+        call = cached_rasterization if (N > 0 and os.environ.get("GSLOC_DROPIN_CACHE", "1") != "0") else fused_rasterization
+        render, alphas, meta = call(
             means, quats, scales, opacities, colors, viewmats[0], Ks[0], width, height, sh_degree=sh_degree,
             render_mode=render_mode, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
             radius_clip=radius_clip, antialiased=(rasterize_mode == "antialiased"))
