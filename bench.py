@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--no-tracker", action="store_true", help="skip the pose-opt iterations/s side measurement")
     ap.add_argument("--no-variants", action="store_true", help="skip the side measurements of the other workload variants")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
+    ap.add_argument("--collective-with-one-rank", action="store_true",
+                    help="dev/test: with --gpus 1, still create an RCCL group of one rank and issue the per-step all-reduce "
+                         "(exercises the captured-collective path on a one-GPU box)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="dev: run the N-rank path with every rank on cuda:0 and a gloo (host) all-reduce")
     args = ap.parse_args()
@@ -410,13 +413,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.collective_with_one_rank:
         import torch.distributed as dist_mod
         dist = dist_mod
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            if "RANK" not in os.environ:  # started without torch.distributed.run (one rank)
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29655")
+                dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+            else:
+                dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from gsplatloc_amd import context as C
@@ -480,23 +488,39 @@ def main():
             dist.all_reduce(pose_grad)
 
     graph = None
+    collective_in_graph = False
     side = torch.cuda.Stream()
     if not args.no_graph:
         with torch.cuda.stream(side):
             for _ in range(2):
                 render_step()
+                if dist is not None:
+                    collective()  # (first use creates the communicator: outside any capture)
             torch.cuda.synchronize()
             trace("eager steps done")
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                render_step()
+            # Over RCCL the all-reduce is captured inside the step's graph (one replay per step, no host dispatch between
+            # the render and the collective); the gloo rehearsal keeps it eager.  GSLOC_CAPTURE_COLLECTIVE=0: eager.
+            if dist is not None and host16 is None and os.environ.get("GSLOC_CAPTURE_COLLECTIVE", "1") != "0":
+                try:
+                    g_all = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_all, stream=side, capture_error_mode="thread_local"):
+                        render_step()
+                        collective()
+                    graph, collective_in_graph = g_all, True
+                except Exception as exc:  # noqa: BLE001 - refused: two dispatches per step, as before
+                    print(f"[bench] all-reduce not captured ({type(exc).__name__}: {exc}); eager collective", file=sys.stderr)
+                    torch.cuda.synchronize()
+            if graph is None:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    render_step()
         torch.cuda.synchronize()
         trace("graph captured")
     render = graph.replay if graph is not None else render_step
 
     def run():
         render()
-        if dist is not None:
+        if dist is not None and not collective_in_graph:
             collective()
 
     for _ in range(args.warmup):
@@ -568,7 +592,9 @@ def main():
                 "intersections_per_gaussian": (n_total / N) if world == 1 else None,
                 "strip_intersections_rank0": n_total, "tile_rows_rank0": list(rows), "gaussians_rank0": n_local,
                 "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
-                "launch": "hipGraph replay" if graph is not None else "eager",
+                "launch": ("hipGraph replay" + (", all-reduce captured in the graph" if collective_in_graph else
+                                                 (", eager all-reduce after the replay" if dist is not None else "")))
+                          if graph is not None else "eager",
                 "backward": backward_name(ctx),
                 "binning": ("keys written into per-tile bins by the projection kernel (sizes from calibrate()), "
                             "register sort per tile" if getattr(ctx, "bins", None) is not None

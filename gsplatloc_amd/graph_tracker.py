@@ -88,6 +88,7 @@ class GraphTracker:
         self._host16 = None
         self._intrinsics = (1.0, 1.0, 0.0, 0.0)
         self.graph = self.graph_tail = None
+        self.collective_captured = False  # True: the all-reduce is a node of self.graph (one replay per iteration)
         self._side = torch.cuda.Stream(device=d)
         self.headroom = 1.5
 
@@ -177,7 +178,7 @@ class GraphTracker:
             dist.all_reduce(self.reduce_buf, group=self.group)
 
     def _iteration(self) -> None:
-        if self.group is None:
+        if self.group is None or (self.graph is not None and self.collective_captured):
             if self.graph is not None:
                 self.graph.replay()
             else:
@@ -198,21 +199,46 @@ class GraphTracker:
         return (self.pose_f, self.pose_i, self.c2w, self.viewmat, self.loss_hist)
 
     def _capture(self) -> None:
-        """One HIP graph per iteration (one rank), or one per half around the collective (several ranks)."""
+        """One HIP graph per iteration.  Several ranks over RCCL: the 16-float all-reduce is captured INSIDE that graph
+        (torch records the RCCL kernel as a node), so an iteration stays one replay; over gloo (the CPU / one-GPU
+        rehearsal) or if the capture is refused, two graphs around an eager collective.
+        GSLOC_CAPTURE_COLLECTIVE=0 forces the two-graph form."""
+        import os
         state = [t.clone() for t in self._state()]
+        want_one = False
+        if self.group is not None and self.reduce_buf.is_cuda and os.environ.get("GSLOC_CAPTURE_COLLECTIVE", "1") != "0":
+            import torch.distributed as dist
+            want_one = dist.get_backend(self.group) == "nccl"
+        self.collective_captured = False
         with torch.cuda.stream(self._side):
-            self._render_and_loss()  # warm-up outside capture
+            self._render_and_loss()  # warm-up outside capture (also creates the communicator on first use)
+            if self.group is not None:
+                self._collective()
             self._pose_step()
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self._side):
-                self._render_and_loss()
-                if self.group is None:
-                    self._pose_step()
-            if self.group is not None:
-                self.graph_tail = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_tail, stream=self._side):
-                    self._pose_step()
+            if want_one:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self._side, capture_error_mode="thread_local"):
+                        self._render_and_loss()
+                        self._collective()
+                        self._pose_step()
+                    self.graph, self.graph_tail, self.collective_captured = g, None, True
+                except Exception as exc:  # noqa: BLE001 - any refusal: fall back to the two-graph form
+                    import warnings
+                    warnings.warn(f"capturing the all-reduce in the iteration graph failed ({type(exc).__name__}: {exc}); "
+                                  "using two graphs around an eager collective")
+                    torch.cuda.synchronize()
+            if not self.collective_captured:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self._side):
+                    self._render_and_loss()
+                    if self.group is None:
+                        self._pose_step()
+                if self.group is not None:
+                    self.graph_tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_tail, stream=self._side):
+                        self._pose_step()
         torch.cuda.synchronize()
         for dst, src in zip(self._state(), state):  # restore what the warm-up and the captures consumed
             dst.copy_(src)
