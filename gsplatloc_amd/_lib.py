@@ -41,9 +41,14 @@ _SIGNATURES = {
     "gsl_fused_bin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P, P, P, P, c_size_t, c_int,
                               P, c_int, P, P, P]),
     "gsl_fused_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, c_int, c_int, P, P, P, P]),
+                                     P, P, P, c_int, c_int, P, P, P, c_int, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, P, P, P, c_int, c_int, P, P, P, P]),
+                                     P, P, P, P, P, P, c_int, c_int, P, P, P, c_int, P]),
+    "gsl_long_ws_bytes": (c_size_t, [c_int]),
+    "gsl_long_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                    P, P, P, c_int, c_int, P, P, c_int, P, c_size_t, c_int, P]),
+    "gsl_long_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
+                                    P, P, P, P, P, P, c_int, c_int, P, P, c_int, P, c_int, P]),
     "gsl_loss_ws_bytes": (c_size_t, [c_int, c_int]),
     "gsl_loss_n_partials": (c_int, [c_int, c_int, c_int, c_int]),
     "gsl_tracking_loss": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P, P, c_size_t,
@@ -64,7 +69,7 @@ _SIGNATURES = {
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P, P, P, P, c_int, c_int,
                                       c_int, c_int, c_int64, P, P, c_int, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                    P, P, P, P, P, P, P, c_int, c_int, P, P]),
+                                    P, P, P, P, P, P, P, c_int, c_int, P, c_int, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "gsl_isect_offsets": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),
     "gsl_rasterize_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P,

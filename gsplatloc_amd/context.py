@@ -23,6 +23,7 @@ from ._lib import check, current_stream, load_library, ptr
 from .fused import _MODES, MAX_STRIP_TILES, alloc_records, tile_n_bits
 
 
+LONG_MIN = 2048   # a tile list longer than this is split over workgroups (segments of 512 entries)
 BIN_BYTES_MAX = 2 << 30  # per-tile key bins larger than this in total: stay with two-pass binning
 TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
 
@@ -102,6 +103,8 @@ class RenderContext:
         self.bins, self.bin_cap = None, 0
         self._counters_dirty = False
         self.trec = self.vcT = None
+        # long tile lists (a pile of splats in one tile): split over workgroups when calibrate() finds one
+        self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes = 0, 0, None, 0
         self.keys = self.flatten_ids = self.hits = None
         if capacity is not None:
             self._alloc_isects(int(capacity))
@@ -123,10 +126,38 @@ class RenderContext:
         self._project(means, quats, scales, opacities, colors, viewmat, K)
         n = int(self.n_is.item())
         self._alloc_isects(int(n * headroom) + 1024)
-        longest = int((self.offs[1:] - self.offs[:-1]).max()) if self.n_tiles else 0
+        sizes = (self.offs[1:] - self.offs[:-1]) if self.n_tiles else self.offs[:0]
+        longest = int(sizes.max()) if self.n_tiles else 0
         self._alloc_bins(int(longest * max(headroom, 1.5)) + 64)
         self._choose_backward()
+        self._alloc_long(sizes, headroom)
         return n
+
+    def _alloc_long(self, sizes: Tensor, headroom: float) -> None:
+        """Long-list mode: on when some tile list comes near LONG_MIN entries (deterministic mode keeps its own
+        backward).  The workspace holds headroom x the segments of every tile that is at least half that long."""
+        self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes = 0, 0, None, 0
+        if self.deterministic or os.environ.get("GSLOC_LONG_LISTS", "1") == "0" or not sizes.numel():
+            return
+        near = sizes[sizes > LONG_MIN // 2]
+        if not near.numel() or int(near.max()) <= int(LONG_MIN * 0.75):
+            return
+        segs = int(torch.ceil(near.double() * max(headroom, 1.5) / 512.0).sum()) + 8
+        self.long_min, self.max_seg = LONG_MIN, segs
+        self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
+        self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
+
+    def grow_long(self, needed: int) -> None:
+        """Recovery after long_overflowed(): a workspace for 1.5 x the segments the frame needed."""
+        self.long_min, self.max_seg = LONG_MIN, int(needed * 1.5) + 8
+        self.long_ws_bytes = self.lib.gsl_long_ws_bytes(self.max_seg)
+        self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
+
+    def long_overflowed(self) -> int:
+        """Host sync: 0, or the number of (tile, segment) pairs a frame needed beyond the long-list workspace."""
+        if self.long_ws is None:
+            return 0
+        return int(self.long_ws[:16].view(torch.int32)[1].item())
 
     def _alloc_bins(self, bin_cap: int) -> None:
         """Fixed-capacity per-tile key bins: the projection kernel then bins directly (no scatter pass, no counter
@@ -194,6 +225,8 @@ class RenderContext:
             raise RuntimeError("a splat outgrew the tiny-splat backward (r_cull >= 2 px); call calibrate() again")
         if self.bins_overflowed():
             raise RuntimeError(f"a tile list outgrew its bin ({self.bins_overflowed()} > {self.bin_cap}); call calibrate() again")
+        if self.long_overflowed():
+            raise RuntimeError(f"long tile lists need {self.long_overflowed()} segments (> {self.max_seg}); call calibrate() again")
         if self.counters_were_dirty():
             raise RuntimeError("a binned projection found the tile counters uncleared (a forward was skipped between two "
                                "projections); call calibrate() again")
@@ -227,9 +260,16 @@ class RenderContext:
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
                                             ptr(self.ws) if self.bins is not None else None, ptr(self.hits),
-                                            current_stream()),
+                                            self.long_min, current_stream()),
               "gsl_fused_raster_fwd")
         self._counters_dirty = False
+        if self.long_min:
+            check(self.lib.gsl_long_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
+                                               self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
+                                               ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
+                                               ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh), ptr(self.hits),
+                                               self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
+                                               current_stream()), "gsl_long_raster_fwd")
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,
@@ -237,11 +277,16 @@ class RenderContext:
                   ptr(self.alphas), ptr(self.last_ids), ptr(v_render), ptr(v_alphas))
         if self.tiny:
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), self.row0, self.row1,
-                                               ptr(self.flags), current_stream()), "gsl_tiny_raster_bwd")
+                                               ptr(self.flags), self.long_min, current_stream()), "gsl_tiny_raster_bwd")
             # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
-                                                ptr(self.vrow), ptr(self.hits), current_stream()), "gsl_fused_raster_bwd")
+                                                ptr(self.vrow), ptr(self.hits), self.long_min, current_stream()),
+                  "gsl_fused_raster_bwd")
+        if self.long_min:  # the segments of the long tiles: rows added to vacc
+            check(self.lib.gsl_long_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh), ptr(self.hits),
+                                               self.long_min, ptr(self.long_ws), self.max_seg, current_stream()),
+                  "gsl_long_raster_bwd")
 
     def _project_bwd(self, full: bool, reduce: bool = True) -> None:
         means, quats, scales, opacities, colors, viewmat, K = self._inputs
@@ -256,7 +301,8 @@ class RenderContext:
         check(self.lib.gsl_fused_project_bwd(
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if self.rgb else None, self.sh_degree,
             self.K_sh, ptr(viewmat), ptr(K), self.N, self.W, self.H, self.eps2d, int(self.antialiased), self.D,
-            ptr(self.radii), ptr(self.Q1), ptr(self.comps), ptr(self.vacc),
+            ptr(self.radii), ptr(self.Q1), ptr(self.comps),
+            ptr(self.vacc) if (not self.tiny or self.long_min) else None,
             ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
             ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
             ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
@@ -302,6 +348,8 @@ class RenderContext:
             return "tile counters were not cleared"
         if self.tiny and st[0]:
             return "a splat outgrew the tiny-splat backward"
+        if self.long_ws is not None and self.long_overflowed():
+            return "long tile lists outgrew their workspace"
         return None
 
     def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None,

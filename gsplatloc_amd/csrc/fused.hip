@@ -743,6 +743,16 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
         }
     } else if (trec) {
       r0 = srow[threadIdx.x][0]; r1 = srow[threadIdx.x][1]; r2 = srow[threadIdx.x][2];
+      if (vacc) {  // tiny-splat mode with long tile lists: those tiles' rows arrive through vacc (gsl_long_raster_bwd)
+        float4 a = vacc[4 * (size_t)i], b = vacc[4 * (size_t)i + 1], c = vacc[4 * (size_t)i + 2];
+        if (a.x != 0.f || a.y != 0.f || a.z != 0.f || a.w != 0.f || b.x != 0.f || b.y != 0.f || b.z != 0.f || b.w != 0.f ||
+            c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f) {
+          r0.x += a.x; r0.y += a.y; r0.z += a.z; r0.w += a.w;
+          r1.x += b.x; r1.y += b.y; r1.z += b.z; r1.w += b.w;
+          r2.x += c.x; r2.y += c.y; r2.z += c.z; r2.w += c.w;
+          vacc[4 * (size_t)i] = z; vacc[4 * (size_t)i + 1] = z; vacc[4 * (size_t)i + 2] = z;
+        }
+      }
     } else {
       r0 = vacc[4 * (size_t)i]; r1 = vacc[4 * (size_t)i + 1]; r2 = vacc[4 * (size_t)i + 2];
       vacc[4 * (size_t)i] = z; vacc[4 * (size_t)i + 1] = z; vacc[4 * (size_t)i + 2] = z;
@@ -962,7 +972,8 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const int32_t* flatten_ids, int64_t capacity, const float* render,
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                         const uint16_t* isect_hits, void* stream);
+                                         const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg,
+                                         void* stream);
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
@@ -977,7 +988,8 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                    const float* render, const float* alphas, const int32_t* last_ids,
                                    const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                                   const void* Qh, float* vrow, const uint16_t* isect_hits, void* stream) {
+                                   const void* Qh, float* vrow, const uint16_t* isect_hits, int long_min,
+                                   void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -1005,7 +1017,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   if (!use_mfma)
     return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                      capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                     isect_hits, stream);
+                                     isect_hits, long_min, nullptr, 0, stream);
 #define CALL_MB(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, false>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,   \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
@@ -1015,6 +1027,26 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
 #undef CALL_MB
   GSL_CHECK_LAUNCH();
   return GSL_OK;
+}
+
+// Compositing backward of the long tile lists (the segments gsl_long_raster_fwd listed in long_ws): adds into vacc.
+extern "C" int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                                   int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                                   const int32_t* flatten_ids, int64_t capacity, const float* render,
+                                   const float* alphas, const int32_t* last_ids, const float* v_render,
+                                   const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
+                                   const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg,
+                                   void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0 || row0 < 0 || row0 > row1 || long_min <= 0 || max_seg <= 0 || !long_ws)
+    return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas || !vacc) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (capacity == 0 || ty0 == ty1 || row0 == row1) return GSL_OK;
+  if (!flatten_ids || (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2)))) return GSL_ERR_BAD_ARG;
+  return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
+                                   capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
+                                   isect_hits, long_min, long_ws, max_seg, stream);
 }
 
 extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,

@@ -287,6 +287,34 @@ __device__ __forceinline__ void tiny_fold_slab(const float4* __restrict__ Q0, co
   }
 }
 
+// ---- long tile lists split over workgroups (raster_px.hip: forward; raster_g16.hip: backward) -----------------------------
+#define GSL_SEG 512
+
+struct LongWs {  // views into the caller's long_ws (sized by gsl_long_ws_bytes)
+  int32_t* n_seg;     // [4]: segments of this frame, max_seg overflow flag, -, -
+  int32_t* seg_tile;  // [max_seg]
+  int32_t* seg_idx;   // [max_seg]  segment number inside its tile
+  int32_t* seg_cnt;   // [max_seg]  segments of that tile
+  float* P;           // [max_seg][256]
+  float* Tend;        // [max_seg][256]
+  int32_t* last;      // [max_seg][256]
+  float* C;           // [max_seg][256][4]
+};
+__host__ __device__ __forceinline__ LongWs long_ws_views(void* ws, int max_seg) {
+  LongWs w;
+  char* p = (char*)ws;
+  w.n_seg = (int32_t*)p; p += 16;
+  w.seg_tile = (int32_t*)p; p += (size_t)max_seg * 4;
+  w.seg_idx = (int32_t*)p; p += (size_t)max_seg * 4;
+  w.seg_cnt = (int32_t*)p; p += (size_t)max_seg * 4;
+  p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+  w.P = (float*)p; p += (size_t)max_seg * 256 * 4;
+  w.Tend = (float*)p; p += (size_t)max_seg * 256 * 4;
+  w.last = (int32_t*)p; p += (size_t)max_seg * 256 * 4;
+  w.C = (float*)p;
+  return w;
+}
+
 // Tile rectangle of a projected Gaussian: [xmin,xmax) x [ymin,ymax) in tiles.
 __device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tile_size, int tile_w,
                                           int tile_h, int& xmin, int& ymin, int& xmax, int& ymax) {

@@ -117,8 +117,8 @@ template <int D, int CG>
 __device__ __forceinline__ void graster_bwd_body(
     GStage<D, CG>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
     const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs,
-    long long re, int tid, float px, float py, float tx0, float ty0, bool inside, int bin_final, float T_final,
-    const float (&vc)[D], float va, const int* __restrict__ bfinal, const uint16_t* __restrict__ isect_hits) {
+    long long re, int tid, float px, float py, float tx0, float ty0, bool inside, int bin_final, float T_init,
+    float Bp_init, const float (&vc)[D], const int* __restrict__ bfinal, const uint16_t* __restrict__ isect_hits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   constexpr int NV = GStage<D, CG>::NV;
@@ -131,8 +131,10 @@ __device__ __forceinline__ void graster_bwd_body(
   const float tcx = tx0 + 8.f, tcy = ty0 + 8.f;
   const float lx = px - tcx, ly = py - tcy;
   const float lxx = lx * lx, lxy = lx * ly, lyy = ly * ly;
-  float T = T_final;
-  float Bp = -T_final * va;
+  // T_init: transmittance after the last entry of [rs, re) this pixel composited; Bp_init: -T_final v_alpha + the
+  // colour partials (dotted with v_colour) of everything this pixel composited BEHIND re (0 entries for a whole list)
+  float T = T_init;
+  float Bp = Bp_init;
   (void)inside;  // a pixel outside the image / pixel-row window has bin_final = -1: no entry passes its age test
   // which slot of the reduce-scatter this lane ends up with, and whether it stores it
   const int myslot = (NS == 8) ? (p >> 1) : p;
@@ -407,18 +409,28 @@ __device__ __forceinline__ void graster_bwd_body(
 // colour sum instead of four, 8 slots per pair, <= 128 VGPRs; CG = D: every other tile.  For D = 4 both kernels are
 // launched and each returns at once on the other's tiles (a workgroup that only reads its tile's v_render costs
 // ~1 ns of a CU): one kernel holding both bodies is limited by the larger one's registers and LDS on every tile.
-template <int D, bool ED, int CG>
+template <int D, bool ED, int CG, bool LONG>
 __global__ __launch_bounds__(256) void k_graster_bwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
-    const uint16_t* __restrict__ isect_hits) {
+    const uint16_t* __restrict__ isect_hits, int long_min, LongWs lw) {
   __shared__ GStage<D, CG> sb;
   __shared__ int s_final[4];
   __shared__ int s_bfinal[16];  // per 4x4 block: last list index any of its pixels composited
-  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  // LONG = false: one workgroup per tile of the strip (tiles with lists longer than long_min are skipped when
+  // long_min > 0); LONG = true: one workgroup per (tile, segment) pair of the long tiles (lw, raster_px.hip)
+  int tile, sgm = 0, gseg = 0;
+  if (LONG) {
+    gseg = blockIdx.x;
+    if (gseg >= lw.n_seg[0]) return;
+    tile = lw.seg_tile[gseg];
+    sgm = lw.seg_idx[gseg];
+  } else {
+    tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  }
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = lane >> 4, p = lane & 15;
   // wave = 8x8 quadrant, DPP row = 4x4 block, lane p of a row = pixel (p & 3, p >> 2) of the block
@@ -430,6 +442,11 @@ __global__ __launch_bounds__(256) void k_graster_bwd(
   long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
   if (re > capacity) re = capacity;
   if (rs >= re) return;
+  if (!LONG && long_min > 0 && re - rs > long_min) return;
+  if (LONG) {
+    rs += (long long)sgm * GSL_SEG;
+    re = min(rs + (long long)GSL_SEG, re);
+  }
 
   size_t pid = inside ? ((size_t)i * W + j) : 0;
   float vc[D];
@@ -466,8 +483,25 @@ __global__ __launch_bounds__(256) void k_graster_bwd(
   // nothing behind block_final was composited by any pixel of the tile: start there
   if ((long long)block_final + 1 < re) re = max((long long)block_final + 1, rs);
   if (rs >= re) return;
+  float T_init = T_final, Bp_init = -T_final * va;
+  if (LONG) {
+    // the pixel went on compositing behind this segment: its T at the segment's end, and the colour partials of the
+    // later segments (the forward left both); otherwise its last entry lies in (or before) this segment: T_final
+    int nseg = lw.seg_cnt[gseg];
+    if (inside && (long long)bin_final >= re) {
+      T_init = fabsf(lw.Tend[(size_t)gseg * 256 + tid]);
+      for (int s2 = sgm + 1; s2 < nseg; ++s2) {
+        size_t slot = (size_t)(gseg - sgm + s2) * 256 + tid;
+        if (lw.Tend[slot] == 2.f) break;  // dead on arrival from there on
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) dot += vc[k] * lw.C[slot * 4 + k];
+        Bp_init += dot;
+      }
+    }
+  }
   graster_bwd_body<D, CG>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, tid, px, py, (float)(txi * 16), (float)(tyi * 16),
-                          inside, bin_final, T_final, vc, va, s_bfinal, isect_hits);
+                          inside, bin_final, T_init, Bp_init, vc, s_bfinal, isect_hits);
 }
 
 }  // namespace gsl
@@ -489,14 +523,27 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const int32_t* flatten_ids, int64_t capacity, const float* render,
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                         const uint16_t* isect_hits, void* stream) {
+                                         const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg,
+                                         void* stream) {
+  // long_ws == NULL: the tiles of the strip (those longer than long_min, if > 0, are skipped);
+  // long_ws != NULL: only the (tile, segment) pairs the forward's long-list pass listed there
   hipStream_t st = (hipStream_t)stream;
-  int nblk = (ty1 - ty0) * tile_w;
+  int nblk = long_ws ? max_seg : (ty1 - ty0) * tile_w;
+  gsl::LongWs lw = gsl::long_ws_views(long_ws ? long_ws : (void*)0, long_ws ? max_seg : 0);
+  const bool lng = long_ws != nullptr;
 #define CALL_G(DD, EE, CC)                                                                                   \
-  hipLaunchKernelGGL((gsl::k_graster_bwd<DD, EE, CC>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,      \
-                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,   \
-                     row0, row1, (const uint4*)Qh, isect_hits)
+  do {                                                                                                       \
+    if (lng)                                                                                                 \
+      hipLaunchKernelGGL((gsl::k_graster_bwd<DD, EE, CC, true>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0, \
+                         (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
+                         flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
+                         row0, row1, (const uint4*)Qh, isect_hits, long_min, lw);                            \
+    else                                                                                                     \
+      hipLaunchKernelGGL((gsl::k_graster_bwd<DD, EE, CC, false>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0, \
+                         (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
+                         flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
+                         row0, row1, (const uint4*)Qh, isect_hits, long_min, lw);                            \
+  } while (0)
   if (channels == 1) { if (ed) CALL_G(1, true, 1); else CALL_G(1, false, 1); }
   else if (channels == 3) { CALL_G(3, false, 3); }
   else if (channels == 4) {

@@ -119,44 +119,22 @@ __device__ __forceinline__ void box_range(float centre_rel, float r, int& lo, in
   hi = (int)fminf(h, 7.f);
 }
 
-template <int D, bool ED>
-__global__ __launch_bounds__(256) void k_praster_fwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-    int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
-    int32_t* __restrict__ clear_state, uint16_t* __restrict__ isect_hits) {
+// The walk of one tile list (or of one SEGMENT [rs, re) of a long list) by the 256 pixels of the tile.
+// MODE 0: composite (the reference loop): pix += feat * alpha * T, T *= 1 - alpha, stop before T would drop to 1e-4.
+// MODE 1: transmittance product only -- T *= 1 - alpha over every entry with alpha >= 1/255, no stop, no colours:
+//         pass A of the long-list split below.
+// On entry: T, done (pixels outside the window, or dead on arrival in a later segment), pix = 0, cur_idx.
+template <int D, int MODE>
+__device__ __forceinline__ void praster_walk(
+    PStage<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
+    const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, long long rs, long long re, int tid, float px,
+    float py, int qx, int qy, int txi, int tyi, bool& done, float& T, float (&pix)[D], int& cur_idx,
+    uint16_t* __restrict__ isect_hits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
-  __shared__ PStage<D> sb;
-  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
-  // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
-  // projection (no clearing launch; sizes of tiles outside the strip are never raised)
-  if (clear_counts && threadIdx.x == 0) {
-    clear_counts[tile] = 0;
-    if (blockIdx.x == 0 && clear_state) *clear_state = 0;  // counters consumed and cleared: the next projection may bin
-  }
-  int tyi = tile / tile_w, txi = tile - tyi * tile_w;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
-  // DPP row g = 4x4 block g of the quadrant; lane p of the row = pixel (p & 3, p >> 2) of the block
-  int grp = lane >> 4, pp = lane & 15;
-  int j = qx + 4 * (grp & 1) + (pp & 3), i = qy + 4 * (grp >> 1) + (pp >> 2);
-  float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
-  bool done = !inside;
-
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs > re) rs = re;
+  const int lane = tid & 63, wv = tid >> 6;
   int nb = (int)((re - rs + 255) / 256);
-
-  float T = 1.f;
-  int cur_idx = 0;
-  float pix[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) pix[k] = 0.f;
-
+  if (MODE == 1) isect_hits = nullptr;
   // isect_hits (may be NULL): per list entry, which of the tile's 16 blocks composited it on at least one pixel
   // (bit 4 * quadrant + row): the compositing backward walks exactly those (block, entry) pairs
   auto flush_hits = [&](int b) {  // after a barrier: every wave has finished batch b
@@ -179,10 +157,10 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     if (tid < bsize) {
       int g = flatten_ids[bstart + tid];
       float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
-      load_record(Q0, Q1, Q2, Qh, g, RGB, r0, r1, r2);
+      load_record(Q0, Q1, Q2, Qh, g, RGB && MODE == 0, r0, r1, r2);
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
-      if (RGB) sb.s2[tid] = r2;
+      if (RGB && MODE == 0) sb.s2[tid] = r2;
     }
     if (isect_hits) {  // (the barrier inside compact_quadrants orders this after flush_hits' reads)
       __syncthreads();
@@ -226,6 +204,11 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
             float sg1 = 0.5f * (u1.x * dx1 * dx1 + u1.z * dy1 * dy1) + u1.y * dx1 * dy1;
             float al0 = fminf(GSL_ALPHA_MAX, p0.w * __expf(-sg0));
             float al1 = fminf(GSL_ALPHA_MAX, u0.w * __expf(-sg1));
+            if (MODE == 1) {
+              if (sg0 >= 0.f && al0 >= GSL_ALPHA_MIN) T *= 1.f - al0;
+              if (two && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN) T *= 1.f - al1;
+              continue;
+            }
             if (sg0 >= 0.f && al0 >= GSL_ALPHA_MIN) {
               float nT = T * (1.f - al0);
               if (nT <= GSL_T_STOP) {
@@ -281,6 +264,60 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     __syncthreads();
     flush_hits(b_done);
   }
+}
+
+// lane -> pixel of the compositing kernels: wave = 8x8 quadrant, DPP row g = 4x4 block g of the quadrant, lane p of
+// the row = pixel (p & 3, p >> 2) of the block
+struct TilePixel {
+  int tyi, txi, qx, qy, i, j;
+};
+__device__ __forceinline__ TilePixel tile_pixel(int tile, int tile_w, int tid) {
+  TilePixel t;
+  int lane = tid & 63, wv = tid >> 6, grp = lane >> 4, pp = lane & 15;
+  t.tyi = tile / tile_w;
+  t.txi = tile - t.tyi * tile_w;
+  t.qx = t.txi * 16 + (wv & 1) * 8;
+  t.qy = t.tyi * 16 + (wv >> 1) * 8;
+  t.j = t.qx + 4 * (grp & 1) + (pp & 3);
+  t.i = t.qy + 4 * (grp >> 1) + (pp >> 2);
+  return t;
+}
+
+// long_min > 0: tiles whose list is longer than long_min entries are left to the long-list kernels below.
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_praster_fwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+    int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
+    int32_t* __restrict__ clear_state, uint16_t* __restrict__ isect_hits, int long_min) {
+  __shared__ PStage<D> sb;
+  int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
+  // projection (no clearing launch; sizes of tiles outside the strip are never raised)
+  if (clear_counts && threadIdx.x == 0) {
+    clear_counts[tile] = 0;
+    if (blockIdx.x == 0 && clear_state) *clear_state = 0;  // counters consumed and cleared: the next projection may bin
+  }
+  int tid = threadIdx.x;
+  TilePixel tp = tile_pixel(tile, tile_w, tid);
+  int i = tp.i, j = tp.j;
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
+  bool done = !inside;
+
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  if (rs > re) rs = re;
+  if (long_min > 0 && re - rs > long_min) return;
+
+  float T = 1.f;
+  int cur_idx = 0;
+  float pix[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pix[k] = 0.f;
+  praster_walk<D, 0>(sb, Q0, Q1, Q2, Qh, flatten_ids, rs, re, tid, px, py, tp.qx, tp.qy, tp.txi, tp.tyi, done, T, pix,
+                     cur_idx, isect_hits);
   if (inside) {
     size_t pid = (size_t)i * W + j;
     float A = 1.f - T;
@@ -290,6 +327,154 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     for (int k = 0; k < D; ++k) render[pid * D + k] = pix[k];
     last_ids[pid] = cur_idx;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Long tile lists split over workgroups (segment transmittances).
+// A pile of splats in one tile -- the invalid pixels of a TUM depth frame all sit at the previous camera's origin
+// (/root/reference/src/data/Image.py:29-35, my_gsplat/geometry.py:138-161 do not filter zero depths) and land on one
+// spot when the camera has moved backwards -- used to be composited by ONE workgroup: 23 k entries, 3.8 + 4.9 ms forward
+// + backward (round 2, scripts/pile_bench.py).  A list longer than long_min entries is now cut into segments of
+// GSL_SEG entries, one workgroup each:
+//   map  : k_long_map lists the (tile, segment) pairs of this frame (device side; the grid is a fixed upper bound);
+//   pass A (k_long_fwd<.., 0>): per pixel, the segment's transmittance product  P_s = prod (1 - alpha)  over its entries
+//          with alpha >= 1/255 (no stop rule, no colours);
+//   pass B (k_long_fwd<.., 1>): the reference loop on the segment, started from  T0 = P_0 ... P_{s-1}  -- a pixel
+//          whose T0 is already <= 1e-4 stopped in an earlier segment (the product only shrinks) and does nothing -- with
+//          the stop rule; leaves the segment's colour partial, its last composited index and T (negative if the pixel
+//          stopped inside);
+//   combine (k_long_combine): adds up a tile's partials in segment order, takes T and the last index of the stopping
+//          (or last) segment, normalises the expected depth and writes the image.
+// The per-pixel sequence of composited splats is the reference's; only the association of the float32 transmittance
+// product changes ((P_0 P_1) x ... instead of one running product), a last-bit effect.  The backward
+// (raster_g16.hip, k_long_bwd) restarts each segment from the stored T and the colour partials of the later segments.
+// ---------------------------------------------------------------------------------------------------
+// One workgroup: the (tile, segment) pairs of every tile of the strip whose list is longer than long_min.
+__global__ __launch_bounds__(1024) void k_long_map(const int32_t* __restrict__ tile_offsets, int tile_begin, int n_strip_tiles,
+                                                   long long capacity, int long_min, int max_seg, LongWs w) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_strip_tiles; base += 1024) {
+    int q = base + tid;
+    int nseg = 0, tile = tile_begin + q;
+    if (q < n_strip_tiles) {
+      long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+      if (re > capacity) re = capacity;
+      long long len = re - rs;
+      if (len > long_min) nseg = (int)((len + GSL_SEG - 1) / GSL_SEG);
+    }
+    int x = nseg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    int first = carry_s + woff + x - nseg;
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+      int g = first + sgm;
+      if (g < max_seg) {
+        w.seg_tile[g] = tile;
+        w.seg_idx[g] = sgm;
+        w.seg_cnt[g] = nseg;
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry_s + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    w.n_seg[0] = min(carry_s, max_seg);
+    if (carry_s > max_seg) w.n_seg[1] = carry_s;  // sticky: more segments than the workspace holds (host polls)
+  }
+}
+
+template <int D, int PASS>
+__global__ __launch_bounds__(256) void k_long_fwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids, long long capacity,
+    int row0, int row1, const uint4* __restrict__ Qh, uint16_t* __restrict__ isect_hits, LongWs w) {
+  __shared__ PStage<D> sb;
+  int g = blockIdx.x;
+  if (g >= w.n_seg[0]) return;
+  int tile = w.seg_tile[g], sgm = w.seg_idx[g];
+  int tid = threadIdx.x;
+  TilePixel tp = tile_pixel(tile, tile_w, tid);
+  int i = tp.i, j = tp.j;
+  float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
+  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+  if (re > capacity) re = capacity;
+  long long ss = rs + (long long)sgm * GSL_SEG, se = min(ss + (long long)GSL_SEG, re);
+  float pix[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pix[k] = 0.f;
+  size_t slot = (size_t)g * 256 + tid;
+  if (PASS == 0) {
+    float T = 1.f;
+    int cur = 0;
+    bool done = !inside;
+    praster_walk<D, 1>(sb, Q0, Q1, Q2, Qh, flatten_ids, ss, se, tid, px, py, tp.qx, tp.qy, tp.txi, tp.tyi, done, T, pix,
+                       cur, nullptr);
+    w.P[slot] = T;
+  } else {
+    float T = 1.f;
+    for (int s = 0; s < sgm; ++s) T *= w.P[(size_t)(g - sgm + s) * 256 + tid];
+    bool dead = !inside || T <= GSL_T_STOP;  // stopped in an earlier segment
+    bool done = dead;
+    int cur = -1;
+    praster_walk<D, 0>(sb, Q0, Q1, Q2, Qh, flatten_ids, ss, se, tid, px, py, tp.qx, tp.qy, tp.txi, tp.tyi, done, T, pix,
+                       cur, isect_hits);
+    // negative: the pixel stopped inside this segment (T is the value before the stop); 2: dead on arrival (a
+    // transmittance is never 2), its T, index and partial are not this segment's to report
+    w.Tend[slot] = dead ? 2.f : ((done && !dead) ? -T : T);
+    w.last[slot] = cur;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w.C[slot * 4 + k] = (k < D) ? pix[k < D ? k : 0] : 0.f;
+  }
+}
+
+template <int D, bool ED>
+__global__ __launch_bounds__(256) void k_long_combine(int W, int H, int tile_w, float* __restrict__ render,
+                                                      float* __restrict__ alphas, int32_t* __restrict__ last_ids, int row0,
+                                                      int row1, LongWs w) {
+  int g = blockIdx.x;
+  if (g >= w.n_seg[0] || w.seg_idx[g] != 0) return;
+  int tile = w.seg_tile[g], nseg = w.seg_cnt[g];
+  int tid = threadIdx.x;
+  TilePixel tp = tile_pixel(tile, tile_w, tid);
+  int i = tp.i, j = tp.j;
+  bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
+  if (!inside) return;
+  float pix[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) pix[k] = 0.f;
+  float T = 1.f;
+  int last = 0;
+  for (int s = 0; s < nseg; ++s) {
+    size_t slot = (size_t)(g + s) * 256 + tid;
+    float t = w.Tend[slot];
+    if (t == 2.f) break;  // dead on arrival: the pixel stopped at the very end of the previous segment
+    int l = w.last[slot];
+#pragma unroll
+    for (int k = 0; k < D; ++k) pix[k] += w.C[slot * 4 + k];
+    if (l >= 0) last = l;
+    T = fabsf(t);
+    if (t < 0.f) break;  // the pixel stopped inside segment s
+  }
+  size_t pid = (size_t)i * W + j;
+  float A = 1.f - T;
+  alphas[pid] = A;
+  if (ED) pix[D - 1] = pix[D - 1] / fmaxf(A, 1e-10f);
+#pragma unroll
+  for (int k = 0; k < D; ++k) render[pid * D + k] = pix[k];
+  last_ids[pid] = last;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -320,7 +505,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float2* __restrict__ trec, float* __restrict__ vcT, int row0, int row1, int32_t* __restrict__ flags) {
+    float2* __restrict__ trec, float* __restrict__ vcT, int row0, int row1, int32_t* __restrict__ flags, int long_min) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ TStage<D> sb;
@@ -353,6 +538,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
   long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
   if (re > capacity) re = capacity;
   if (rs >= re) return;
+  if (long_min > 0 && re - rs > long_min) return;  // long list: gsl_long_raster_bwd adds this tile's rows to vacc
   int wave_final = bin_final;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) wave_final = max(wave_final, __shfl_xor(wave_final, o, 64));
@@ -448,7 +634,7 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
                                    const int32_t* flatten_ids, int64_t capacity, const float* render,
                                    const float* alphas, const int32_t* last_ids, const float* v_render,
                                    const float* v_alphas, float* trec, float* vcT, int row0, int row1,
-                                   int32_t* flags, void* stream) {
+                                   int32_t* flags, int long_min, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -464,7 +650,7 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
   hipLaunchKernelGGL((gsl::k_tiny_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,            \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas,         \
-                     (float2*)trec, vcT, row0, row1, flags)
+                     (float2*)trec, vcT, row0, row1, flags, long_min)
   if (channels == 1) { if (ed) CALL_TB(1, true); else CALL_TB(1, false); }
   else if (channels == 3) { CALL_TB(3, false); }
   else if (channels == 4) { if (ed) CALL_TB(4, true); else CALL_TB(4, false); }
@@ -487,7 +673,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
                                  int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws,
-                                 uint16_t* isect_hits, void* stream) {
+                                 uint16_t* isect_hits, int long_min, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -503,9 +689,51 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
-                     (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits)
+                     (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits, long_min)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+// ---- long tile lists (see the comment above k_long_map) ----------------------------------------------------------------
+extern "C" size_t gsl_long_ws_bytes(int max_seg) {
+  if (max_seg <= 0) return 0;
+  size_t b = 16 + (size_t)3 * max_seg * 4 + 256;
+  return b + (size_t)max_seg * 256 * 4 * (1 + 1 + 1 + 4);
+}
+
+extern "C" int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                                   int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                                   const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
+                                   int32_t* last_ids, int row0, int row1, const void* Qh, uint16_t* isect_hits,
+                                   int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, void* stream) {
+  if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
+      capacity < 0 || row0 < 0 || row0 > row1 || long_min <= 0 || max_seg <= 0)
+    return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !render || !alphas || !last_ids || !long_ws) return GSL_ERR_BAD_ARG;
+  if (long_ws_bytes < gsl_long_ws_bytes(max_seg)) return GSL_ERR_WORKSPACE;
+  if (capacity > 0 && (!flatten_ids || (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))))) return GSL_ERR_BAD_ARG;
+  if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (ty0 == ty1 || capacity == 0) return GSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  gsl::LongWs w = gsl::long_ws_views(long_ws, max_seg);
+  hipLaunchKernelGGL(gsl::k_long_map, dim3(1), dim3(1024), 0, st, tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w,
+                     (long long)capacity, long_min, max_seg, w);
+  GSL_CHECK_LAUNCH();
+#define CALL_LF(DD, EE)                                                                                          \
+  do {                                                                                                           \
+    hipLaunchKernelGGL((gsl::k_long_fwd<DD, 0>), dim3(max_seg), dim3(256), 0, st, (const float4*)Q0,             \
+                       (const float4*)Q1, (const float4*)Q2, width, height, tile_w, tile_offsets, flatten_ids,   \
+                       (long long)capacity, row0, row1, (const uint4*)Qh, isect_hits, w);                        \
+    hipLaunchKernelGGL((gsl::k_long_fwd<DD, 1>), dim3(max_seg), dim3(256), 0, st, (const float4*)Q0,             \
+                       (const float4*)Q1, (const float4*)Q2, width, height, tile_w, tile_offsets, flatten_ids,   \
+                       (long long)capacity, row0, row1, (const uint4*)Qh, isect_hits, w);                        \
+    hipLaunchKernelGGL((gsl::k_long_combine<DD, EE>), dim3(max_seg), dim3(256), 0, st, width, height, tile_w,    \
+                       render, alphas, last_ids, row0, row1, w);                                                 \
+  } while (0)
+  GSL_P_DISPATCH(channels, ed, CALL_LF)
+#undef CALL_LF
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -79,7 +79,7 @@ class _FusedRasterization(torch.autograd.Function):
         hits = torch.empty(cap, dtype=torch.int16, device=dev)  # blocks of its tile that composited each list entry
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
-                                       ptr(last_ids), 0, H, None, None, ptr(hits), st), "gsl_fused_raster_fwd")
+                                       ptr(last_ids), 0, H, None, None, ptr(hits), 0, st), "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
                               comps if antialiased else torch.empty(0, device=dev), offs, flatten_ids, render,
@@ -115,7 +115,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(vacc), 0, H, None, None, ptr(hits), st), "gsl_fused_raster_bwd")
+                                       ptr(vacc), 0, H, None, None, ptr(hits), 0, st), "gsl_fused_raster_bwd")
         ni = ctx.needs_input_grad
         full = any(ni[:5])
         v_means = v_quats = v_scales = v_opac = v_colors = None

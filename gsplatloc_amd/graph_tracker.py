@@ -244,14 +244,14 @@ class GraphTracker:
             dst.copy_(src)
 
     # ------------------------------------------------------------------ frame loop
-    def _poll(self) -> Tuple[int, int, int, int]:
+    def _poll(self) -> Tuple[int, int, int, int, int]:
         """The only host sync of the loop: (stopped, intersections beyond the capacity or 0, a splat outgrew the tiny
-        backward, longest tile list that outgrew its bin or 0).  With several ranks the four numbers are MAX-reduced
+        backward, longest tile list that outgrew its bin or 0, segments of long tile lists beyond their workspace or 0).  With several ranks the four numbers are MAX-reduced
         over the group, so every rank takes the same decision at the same iteration: a rank that re-ran the frame on
         its own while the others returned would pair its all-reduces with those of a different iteration or frame."""
         n_is = int(self.rc.n_is.item())
         local = [int(self.pose_i[2].item()), n_is if n_is > self.rc.capacity else 0, int(self.rc.tiny_overflowed()),
-                 int(self.rc.bins_overflowed())]
+                 int(self.rc.bins_overflowed()), int(self.rc.long_overflowed())]
         if self.group is None:
             return tuple(local)
         import torch.distributed as dist
@@ -272,8 +272,8 @@ class GraphTracker:
                 for _ in range(n):
                     self._iteration()
                 done += n
-                stopped, n_over, tiny_over, bin_over = self._poll()
-                if n_over or tiny_over or bin_over:
+                stopped, n_over, tiny_over, bin_over, long_over = self._poll()
+                if n_over or tiny_over or bin_over or long_over:
                     redo = True
                     break
                 if stopped:
@@ -288,6 +288,9 @@ class GraphTracker:
             own_bins = self.rc.bins_overflowed()
             if own_bins:
                 self.rc.grow_bins(own_bins)
+            own_long = self.rc.long_overflowed()
+            if own_long:
+                self.rc.grow_long(own_long)
             n_is = int(self.rc.n_is.item())
             if n_is > self.rc.capacity:
                 self.headroom *= 1.5

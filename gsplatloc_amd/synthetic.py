@@ -96,7 +96,7 @@ def frame_pair(W: int = 160, H: int = 120, rot_deg: float = 0.5, trans: float = 
 
 
 def depth_frame_scene(W: int = 640, H: int = 480, stride: int = 1, holes: bool = False, device="cuda", seed: int = 3,
-                      hole_frac: float = 0.08) -> Dict:
+                      hole_frac: float = 0.08, pile: bool = False) -> Dict:
     """Workloads S / T of SURVEY.md 8(d): the Gaussians GsplatLoc builds from one depth frame
     (/root/reference/src/data/Image.py:29-35, my_gsplat/geometry.py:44-66,138-161): every ``stride``-th pixel of a
     synthetic room depth image back-projected in raster order, isotropic scales from the 4 nearest neighbours as the
@@ -105,12 +105,14 @@ def depth_frame_scene(W: int = 640, H: int = 480, stride: int = 1, holes: bool =
     near plane.  Rendered from the frame pair's second pose, chosen so that the camera has moved FORWARD: the invalid
     points then lie behind the near plane as SURVEY.md A.7 describes the usual case (with a sideways or backward
     step they are splatted as one enormous pile at the image centre -- handled, tests/test_gpu_configs.py has that
-    frame, but it measures the pile, not the frame).  Needs the GPU (k-NN kernels)."""
+    frame, but it measures the pile, not the frame; ``pile=True`` selects exactly that step: the invalid points pass
+    the near plane and land on one spot, ~23 k entries in one tile list at 640x480).  Needs the GPU (k-NN kernels)."""
     from .my_gsplat.geometry import depth_to_points, init_gs_scales
 
     fp = frame_pair(W, H, rot_deg=0.4, trans=0.015, seed=seed)
     c2w1 = fp["c2w1"].clone()
-    if float((-c2w1[:3, :3].T @ c2w1[:3, 3])[2]) > 0:  # world origin in front of the second camera: step the other way
+    in_front = float((-c2w1[:3, :3].T @ c2w1[:3, 3])[2]) > 0  # world origin in front of the second camera
+    if in_front != pile:  # step the other way
         c2w1[:3, 3] = -c2w1[:3, 3]
     fp["c2w1"] = c2w1
     depth = fp["depth0"].clone()

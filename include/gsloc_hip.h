@@ -218,13 +218,34 @@ int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int 
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
-                         void* binned_ws, uint16_t* isect_hits, void* stream);
+                         void* binned_ws, uint16_t* isect_hits, int long_min, void* stream);
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                         const void* Qh, float* vrow, const uint16_t* isect_hits, void* stream);
+                         const void* Qh, float* vrow, const uint16_t* isect_hits, int long_min, void* stream);
+/* Long tile lists split over workgroups (long_min > 0 in the calls above and in gsl_tiny_raster_bwd: tiles whose list
+ * is longer than long_min entries are skipped there and handled here).  A pile of splats in one tile -- the invalid
+ * pixels of a TUM depth frame, /root/reference/src/data/Image.py:29-35 -- is cut into segments of 512 entries, one
+ * workgroup each: the forward computes per-pixel segment transmittances, restarts every segment from the product of
+ * the earlier ones and combines the partial images; the backward restarts every segment from the stored state.
+ * long_ws: gsl_long_ws_bytes(max_seg) bytes, zero-filled once; max_seg bounds the (tile, segment) pairs of a frame
+ * (if a frame has more, long_ws[1] (int32) is set to the number needed: poll it, grow, re-run).  Call
+ * gsl_long_raster_fwd after gsl_fused_raster_fwd, gsl_long_raster_bwd after gsl_fused_raster_bwd / gsl_tiny_raster_bwd
+ * (it adds into vacc; gsl_fused_project_bwd given both tiny_trec and vacc consumes both). */
+size_t gsl_long_ws_bytes(int max_seg);
+int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                        int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                        const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
+                        int32_t* last_ids, int row0, int row1, const void* Qh, uint16_t* isect_hits,
+                        int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, void* stream);
+int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
+                        int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
+                        const int32_t* flatten_ids, int64_t capacity, const float* render,
+                        const float* alphas, const int32_t* last_ids, const float* v_render,
+                        const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
+                        const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg, void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,
@@ -250,7 +271,7 @@ int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int c
                         const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                         const float* render, const float* alphas, const int32_t* last_ids,
                         const float* v_render, const float* v_alphas, float* trec, float* vcT,
-                        int row0, int row1, int32_t* flags, void* stream);
+                        int row0, int row1, int32_t* flags, int long_min, void* stream);
 
 /* ---- tracker tail: loss + pose update on device (csrc/tracker.hip) ----
  * Replaces the PyTorch/kornia glue of one iteration of GsplatLoc's Runner.train

@@ -276,3 +276,51 @@ def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
     # bound follows the measured floor but is capped, and the floor itself is bounded (tests/parity.py).
     assert floor32 < FLOOR32_MAX, floor32
     assert err < max(POSE_GRAD_TOL, min(2.0 * floor32, 1e-3)), (err, floor32)
+
+
+def test_long_tile_list_is_split_over_workgroups_and_matches_the_oracle():
+    """VERDICT r2 'missing' 1: the pile.  A TUM-like frame seen from a camera that has moved BACKWARDS: the invalid
+    (zero-depth) points, which all sit at the previous camera's origin (/root/reference/src/data/Image.py:29-35,
+    my_gsplat/geometry.py:138-161), pass the near plane and land on one spot: ~23 k entries in one tile list.  That list
+    is cut into segments composited by separate workgroups (segment transmittances; raster_px.hip / raster_g16.hip).
+    Render, alpha and every gradient against the float64 oracle, and against the single-workgroup path of round 2
+    (GSLOC_LONG_LISTS=0)."""
+    import os
+
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=1, holes=True, device=dev, pile=True)
+    N = sc["means"].shape[0]
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
+    v = _depth_upstream(H, W, seed=9).float().to(dev).contiguous()
+    va = torch.zeros(H, W, 1, device=dev)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["GSLOC_LONG_LISTS"] = mode
+        try:
+            ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+            ctx.calibrate(*inp)
+        finally:
+            os.environ.pop("GSLOC_LONG_LISTS", None)
+        longest = int((ctx.offs[1:] - ctx.offs[:-1]).max())
+        assert longest > 20_000, longest
+        assert (ctx.long_min > 0) == (mode == "1")
+        render, alphas = ctx.forward(*inp)
+        g = ctx.backward(v, va, full=True)
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        out[mode] = (render.clone(), alphas.clone(), ctx.last_ids.clone(), g["viewmat"].clone(), g["means"].clone())
+    (r1, a1, l1, gv1, gm1), (r0, a0, l0, gv0, gm0) = out["1"], out["0"]
+    # same per-pixel sequence of composited splats; only the association of the transmittance product differs
+    assert float((l1 != l0).float().mean()) < 1e-4
+    assert float((r1 - r0).abs().max()) < 1e-4 and float((a1 - a0).abs().max()) < 1e-5
+    assert rel_inf(gv1[:3], gv0[:3]) < 1e-4, rel_inf(gv1[:3], gv0[:3])
+    assert float((gm1 - gm0).norm() / gm0.norm()) < 1e-4
+    # and the split path against the oracle, like every other configuration
+    cpu = {k: sc[k].cpu() for k in ("means", "quats", "scales", "opacities", "sh", "K")}
+    errs = _context_vs_c_oracle(f"pile N={N} 640x480, longest tile list {longest}", cpu, sc["viewmat"].cpu(), W, H,
+                                [_depth_upstream(H, W, seed=k) for k in (9, 10, 11)], 5e-3)
+    assert errs["v_viewmat"] < 8e-4

@@ -15,7 +15,7 @@ CANARY = 0xA5
 
 WRITABLE = ["radii", "Q0", "Q1", "Q2", "comps", "offs", "n_is", "ws", "render", "alphas", "last_ids", "vacc",
             "v_viewmat", "v_means", "v_quats", "v_scales", "v_opacities", "v_colors", "keys", "flatten_ids", "hits", "trec",
-            "vcT"]
+            "vcT", "long_ws"]
 
 
 def _rehome(ctx):
@@ -73,6 +73,32 @@ def test_no_write_outside_buffers(N, W, H, sigma_px, rows, mode, full):
     for _ in range(3):
         ctx.forward(*inp)
         ctx.backward(v, va, full=full)
+    torch.cuda.synchronize()
+    ctx.check_capacity()
+    _check(homes)
+    assert torch.isfinite(ctx.v_viewmat).all()
+
+
+def test_no_write_outside_buffers_with_a_long_tile_list():
+    """The same canaries around a frame whose invalid points pile up in one tile (long-list split active)."""
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=1, holes=True, device=dev, pile=True)
+    N = sc["means"].shape[0]
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
+    ctx.calibrate(*inp, headroom=1.05)
+    assert ctx.long_min > 0
+    homes = _rehome(ctx)
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(H, W, ctx.D, generator=g).to(dev)
+    va = torch.randn(H, W, 1, generator=g).to(dev)
+    for _ in range(3):
+        ctx.forward(*inp)
+        ctx.backward(v, va, full=True)
     torch.cuda.synchronize()
     ctx.check_capacity()
     _check(homes)
