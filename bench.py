@@ -50,7 +50,7 @@ WORKLOADS = {
     # as-coded kNN^2 scales (sigma_px -> 0): ref/src/data/Image.py:29,35, my_gsplat/geometry.py:60-64, cam_params.json:3-4
     "D": dict(n=816_000, width=1200, height=680, kind="depth_frame", stride=1, holes=False),
 }
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def parse():
@@ -156,7 +156,8 @@ def implementation_bin_bytes(N, I, n_tiles):
 
 STAGE_KERNELS = {  # stage timer -> kernels it brackets (names as rocprofv3 prints them, template arguments dropped)
     "project_fwd": ("k_fproject<true, true>", "k_fproject<false, true>"), "bin": ("k_tile_sort",),
-    "raster_fwd": ("k_praster_fwd",), "raster_bwd": ("k_mraster_bwd", "k_tiny_bwd"),
+    "raster_fwd": ("k_praster_fwd", "k_long_fwd", "k_long_combine", "k_long_map"),
+    "raster_bwd": ("k_graster_bwd", "k_mraster_bwd", "k_tiny_bwd"),
     "project_bwd": ("k_fproject_bwd", "k_freduce_viewmat"),
 }
 
@@ -168,7 +169,15 @@ def pmc_traffic(stage):
     path = os.path.join(ROOT, PMC_SUMMARY)
     if not os.path.exists(path):
         return None
-    ks = json.load(open(path))["kernels"]
+    summary = json.load(open(path))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from pmc_summary import csrc_sha
+        if summary.get("csrc_sha") != csrc_sha():
+            return None  # the counters were collected on other kernel sources: not this build's traffic
+    except Exception:  # noqa: BLE001
+        return None
+    ks = summary["kernels"]
     tot = [v["hbm_bytes"] for k, v in ks.items() if any(k.startswith(p) for p in STAGE_KERNELS.get(stage, ()))]
     return sum(tot) if tot else None
 
@@ -233,22 +242,42 @@ def cpu_baseline(args, scene, gpu):
         rt, at = (1e-4, 2e-5) if args.staging == "fp32" else (3e-3, 3e-4)
         ok = (np.abs(rg - ref["render"]) <= at + rt * np.abs(ref["render"])).all(-1) & (
             np.abs(ag - ref["alphas"]) <= at + rt * np.abs(ref["alphas"]))
-        vm = v * ok[..., None]
-        want = step("f64", vm)
-        got = gpu["backward"](torch.from_numpy(vm))
-        gv, wv = got.cpu().double().numpy()[:3], want["v_viewmat"][:3]
+        # pose gradient over three upstream gradients (white noise on the depth channel, seeds 1..3; the first is the
+        # timed step's): HIP against the float64 oracle (max over the seeds), HIP against the oracle's own float32 build
+        # (like for like) and that build against float64 (the float32 floor of this configuration).  The bound applied is
+        # the tests' (tests/parity.py): 1e-4, or min(2 x floor, 8e-4) where the floor itself is above 5e-5.
+        worst = vs32 = floor32 = 0.0
+        for seed in (1, 2, 3):
+            if seed == 1:
+                vk = v
+            else:
+                gk = torch.Generator().manual_seed(seed)
+                vk = np.zeros_like(v)
+                vk[..., 3] = torch.randn(h, w, generator=gk).numpy()
+            vm = vk * ok[..., None]
+            want, want32 = step("f64", vm), step("f32", vm)
+            got = gpu["backward"](torch.from_numpy(vm))
+            gv = got.cpu().double().numpy()[:3]
+            w64, w32 = want["v_viewmat"][:3], want32["v_viewmat"][:3].astype(np.float64)
+            worst = max(worst, float(np.abs(gv - w64).max() / np.abs(w64).max()))
+            vs32 = max(vs32, float(np.abs(gv - w32).max() / np.abs(w32).max()))
+            floor32 = max(floor32, float(np.abs(w32 - w64).max() / np.abs(w64).max()))
+        bound = max(1e-4, min(2.0 * floor32, 8e-4)) if args.staging == "fp32" else None
         parity = {"against": "oracle/csrc/gsplat_oracle.c float64",
-                  "tolerance": "1e-4 relative (north_star)" if args.staging == "fp32" else
+                  "tolerance": ("images: 1e-4 relative + 2e-5 absolute (north_star's 1e-4); pose gradient: "
+                                f"{bound:.1e} = max(1e-4, min(2 x float32 floor, 8e-4)) of its largest entry, flip-aware")
+                               if args.staging == "fp32" else
                                "fp16-staged records: ~1e-3 relative expected (half has 11 significant bits)",
                   "depth_rel_err": {"mean": float(d_rel.mean()), "p99": float(np.quantile(d_rel.reshape(-1)[::7], 0.99)),
                                     "max_over_agreeing_pixels": float(d_rel[ok].max())},
                   "alpha_abs_err": {"mean": float(np.abs(ag - ref["alphas"]).mean()),
                                     "max_over_agreeing_pixels": float(np.abs(ag - ref["alphas"])[ok].max())},
                   "pixels_beyond_tolerance": float(1.0 - ok.mean()),
-                  "v_viewmat_rel_err": float(np.abs(gv - wv).max() / np.abs(wv).max()),
-                  "v_viewmat_note": "upstream gradient = white noise on the depth channel: a sum of ~1e6 terms of random "
-                                    "sign (poorly conditioned); tests/test_gpu_configs.py measures this number and the "
-                                    "tracker-loss gradient next to the float32 floor of the oracle's own float32 build",
+                  "v_viewmat_rel_err": worst, "v_viewmat_seeds": 3,
+                  "v_viewmat_vs_f32_oracle": vs32, "v_viewmat_f32_oracle_vs_f64": floor32,
+                  "v_viewmat_within_bound": (worst < bound) if bound is not None else None,
+                  "v_viewmat_note": "max over 3 white-noise upstream gradients (a sum of ~1e6 terms of random sign); the "
+                                    "oracle's float32 build differs from its float64 build by v_viewmat_f32_oracle_vs_f64",
                   "n_isects": [int(gpu["n_isects"]), int(ref["n_isects"])]}
     return base, parity
 
@@ -284,7 +313,11 @@ def cpu_baseline_torch(args, cores, V, reason):
 
 
 def backward_name(ctx):
-    return "tiny-splat slabs, folded inside the projection backward" if getattr(ctx, "tiny", False) else "quadrant walk + MFMA pixel sums"
+    if getattr(ctx, "tiny", False):
+        return "tiny-splat slabs, folded inside the projection backward"
+    if getattr(ctx, "deterministic", False):
+        return "quadrant walk + MFMA pixel sums (deterministic)"
+    return "16-lane groups: each DPP row walks its 4x4 block's list (pairs from the forward's hit masks)"
 
 
 def event_stats(ms):
@@ -605,7 +638,8 @@ def main():
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": (achieved / 8000.0) if achieved else None,
                 "traffic": pmc_traffic(dom) if (world == 1 and headline and N == 1_000_000) else None,
-                "traffic_source": f"committed rocprofv3 --pmc summary {PMC_SUMMARY} of this command (not measured in this run)",
+                "traffic_source": f"rocprofv3 --pmc summary {PMC_SUMMARY} of this command, quoted only while its kernel-source "
+                                  "hash matches this build (counters cannot be read from inside the process)",
                 "algorithmic_bytes_per_launch": bytes_stage[dom], "avg_launch_ms": dom_ms,
                 "whole_step": {"model": "SURVEY.md 8(d)", "algorithmic_bytes": sum(bytes_stage.values()),
                                "achieved_GBps": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9,

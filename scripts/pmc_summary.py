@@ -9,9 +9,22 @@ calibrates that factor on wide streaming reads only, so for the 16-B gathers of 
 doubled figure is an upper estimate.
 """
 import csv
+import glob
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+
+def csrc_sha():
+    """Hash of the kernel sources the counters were collected on: bench.py only quotes roofline.traffic from a summary
+    whose hash matches the library it runs (a committed constant goes stale the moment a kernel changes)."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gsplatloc_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -37,7 +50,7 @@ def main():
         wb = write.get(k, (0.0, 0))[0] * 1024.0
         out[k] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
                   "launches": max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])}
-    json.dump({"note": "mean per launch; fetch = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write = WRITE_SIZE KiB x 1024",
+    json.dump({"csrc_sha": csrc_sha(), "note": "mean per launch; fetch = FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), write = WRITE_SIZE KiB x 1024",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         print(f"{k:48s} fetch {v['fetch_bytes']/1e6:9.1f} MB  write {v['write_bytes']/1e6:9.1f} MB  x{v['launches']}")
