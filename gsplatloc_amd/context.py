@@ -139,17 +139,22 @@ class RenderContext:
         self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes = 0, 0, None, 0
         if self.deterministic or os.environ.get("GSLOC_LONG_LISTS", "1") == "0" or not sizes.numel():
             return
-        near = sizes[sizes > LONG_MIN // 2]
-        if not near.numel() or int(near.max()) <= int(LONG_MIN * 0.75):
+        # "long" is relative to the frame: four times its mean (non-empty) list, at least LONG_MIN entries -- workload X
+        # has ordinary lists of ~1 500 entries, and launching the long-list kernels over empty segment grids would cost it
+        # 4 % for nothing
+        nonempty = sizes[sizes > 0]
+        long_min = max(LONG_MIN, int(4.0 * float(nonempty.double().mean()))) if nonempty.numel() else LONG_MIN
+        near = sizes[sizes > long_min // 2]
+        if not near.numel() or int(near.max()) <= int(long_min * 0.75):
             return
         segs = int(torch.ceil(near.double() * max(headroom, 1.5) / 512.0).sum()) + 8
-        self.long_min, self.max_seg = LONG_MIN, segs
+        self.long_min, self.max_seg = long_min, segs
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
     def grow_long(self, needed: int) -> None:
         """Recovery after long_overflowed(): a workspace for 1.5 x the segments the frame needed."""
-        self.long_min, self.max_seg = LONG_MIN, int(needed * 1.5) + 8
+        self.long_min, self.max_seg = max(self.long_min, LONG_MIN), int(needed * 1.5) + 8
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(self.max_seg)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
