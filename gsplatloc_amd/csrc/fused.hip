@@ -1012,21 +1012,10 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
     GSL_CHECK_LAUNCH();
     return GSL_OK;
   }
-  // default: 16-lane-group walk (raster_g16.hip); GSLOC_BWD_KERNEL=mfma selects the quadrant walk + MFMA sums (dev switch)
-  static const bool use_mfma = [] { const char* e = getenv("GSLOC_BWD_KERNEL"); return e && !strcmp(e, "mfma"); }();
-  if (!use_mfma)
-    return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
-                                     capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                     isect_hits, long_min, nullptr, 0, stream);
-#define CALL_MB(DD, EE)                                                                                       \
-  hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, false>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,   \
-                     (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
-                     flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc,    \
-                     row0, row1, (const uint4*)Qh)
-  GSL_F_DISPATCH(channels, ed, CALL_MB)
-#undef CALL_MB
-  GSL_CHECK_LAUNCH();
-  return GSL_OK;
+  // non-deterministic path: 16-lane groups, one workgroup per quadrant (raster_g16.hip)
+  return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
+                                   capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
+                                   isect_hits, long_min, nullptr, 0, stream);
 }
 
 // Compositing backward of the long tile lists (the segments gsl_long_raster_fwd listed in long_ws): adds into vacc.

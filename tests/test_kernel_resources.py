@@ -1,6 +1,6 @@
 """Register / LDS budget of the hot kernels, from hipcc's resource remarks (no GPU needed): the compositing kernels
-are occupancy-sensitive (a refactor that pushed k_mraster_bwd from 120 to 130 registers cost 17 % on hardware), so the
-budget is pinned here."""
+are occupancy-sensitive (round 2: k_mraster_bwd from 120 to 130 registers cost 17 % on hardware; round 3: the
+per-quadrant backward at 9.8 KB of LDS -- 4 waves/SIMD -- ran 264 us, at 8.4 KB 257 us), so the budget is pinned here."""
 import os
 import re
 import subprocess
@@ -33,11 +33,15 @@ def _resources(src):
 def test_compositing_kernels_keep_their_occupancy():
     fused = _resources("fused.hip")
     px = _resources("raster_px.hip")
-    bwd = [v for k, v in fused.items() if "k_mraster_bwdILi4ELb1ELb0" in k]   # RGB+ED, atomic (default) backward
+    g16 = _resources("raster_g16.hip")
+    # RGB+ED backward, depth-only upstream gradient (GsplatLoc's loss): one wave per workgroup, >= 4.75 waves/SIMD by
+    # LDS (19 workgroups of <= 8.5 KB per CU) and <= 96 registers
+    bwd = [v for k, v in g16.items() if "k_qraster_bwdILi4ELb1ELi1ELb0" in k]
     assert len(bwd) == 1
     b = bwd[0]
-    assert b["ScratchSize"] == 0 and b["VGPRs"] + b.get("AGPRs", 0) <= 128 and b["Occupancy"] >= 4, b
-    assert b["LDS"] <= 40 * 1024, b                                            # four workgroups per CU
+    assert b["ScratchSize"] == 0 and b["VGPRs"] + b.get("AGPRs", 0) <= 96 and b["LDS"] <= 8704, b
+    full = [v for k, v in g16.items() if "k_qraster_bwdILi4ELb1ELi4ELb0" in k][0]  # full-colour tiles
+    assert full["ScratchSize"] == 0 and full["VGPRs"] <= 128 and full["LDS"] <= 12 * 1024, full
     det = [v for k, v in fused.items() if "k_mraster_bwdILi4ELb1ELb1" in k][0]  # deterministic variant: may be slower,
     assert det["ScratchSize"] == 0 and det["LDS"] <= 64 * 1024, det            # must not spill, two workgroups per CU
     fwd = [v for k, v in px.items() if "k_praster_fwdILi4ELb1" in k][0]
