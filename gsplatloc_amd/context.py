@@ -75,6 +75,7 @@ class RenderContext:
         # size, [3] a binned projection started on uncleared tile counters
         self.status = torch.zeros(8, dtype=i32, device=dev)
         self.n_is = self.status[4:5]
+        self.hit_counts = torch.zeros(4 * self.n_tiles, dtype=i32, device=dev)  # lengths of the quadrants' hit lists
         self.ws_bytes = self.lib.gsl_fused_ws_bytes(N, self.n_tiles)
         self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.render = torch.zeros(self.H, self.W, self.D, dtype=f32, device=dev)
@@ -115,8 +116,8 @@ class RenderContext:
         self.capacity = max(int(capacity), 1)
         self.keys = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
         self.flatten_ids = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
-        # per list entry: the blocks of its tile that composited it (written by the forward, read by the backward)
-        self.hits = torch.zeros(self.capacity, dtype=torch.int16, device=self.device)
+        # per tile and quadrant: the list entries its pixels composited (written by the forward, read by the backward)
+        self.hits = torch.zeros(4 * self.capacity, dtype=torch.int32, device=self.device)
         if self.deterministic:
             self.vrow = torch.zeros(self.capacity, 16, dtype=torch.float32, device=self.device)
 
@@ -265,7 +266,7 @@ class RenderContext:
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
                                             ptr(self.ws) if self.bins is not None else None, ptr(self.hits),
-                                            self.long_min, current_stream()),
+                                            ptr(self.hit_counts), self.long_min, current_stream()),
               "gsl_fused_raster_fwd")
         self._counters_dirty = False
         if self.long_min:
@@ -286,7 +287,8 @@ class RenderContext:
             # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
-                                                ptr(self.vrow), ptr(self.hits), self.long_min, current_stream()),
+                                                ptr(self.vrow), ptr(self.hits), ptr(self.hit_counts), self.long_min,
+                                                current_stream()),
                   "gsl_fused_raster_bwd")
         if self.long_min:  # the segments of the long tiles: rows added to vacc
             check(self.lib.gsl_long_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh), ptr(self.hits),

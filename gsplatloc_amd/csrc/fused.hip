@@ -972,8 +972,8 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const int32_t* flatten_ids, int64_t capacity, const float* render,
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                         const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg,
-                                         void* stream);
+                                         const uint32_t* isect_hits, const int32_t* isect_hit_counts, int long_min,
+                                         void* long_ws, int max_seg, void* stream);
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
@@ -988,8 +988,8 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                                    const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                                    const float* render, const float* alphas, const int32_t* last_ids,
                                    const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                                   const void* Qh, float* vrow, const uint16_t* isect_hits, int long_min,
-                                   void* stream) {
+                                   const void* Qh, float* vrow, const uint32_t* isect_hits,
+                                   const int32_t* isect_hit_counts, int long_min, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -998,6 +998,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (capacity == 0 || ty0 == ty1 || row0 == row1) return GSL_OK;
   if (!flatten_ids || (!vacc && !vrow)) return GSL_ERR_BAD_ARG;
+  if (isect_hits && !isect_hit_counts) return GSL_ERR_BAD_ARG;
   if (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
@@ -1015,7 +1016,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   // non-deterministic path: 16-lane groups, one workgroup per quadrant (raster_g16.hip)
   return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                    capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                   isect_hits, long_min, nullptr, 0, stream);
+                                   isect_hits, isect_hit_counts, long_min, nullptr, 0, stream);
 }
 
 // Compositing backward of the long tile lists (the segments gsl_long_raster_fwd listed in long_ws): adds into vacc.
@@ -1024,7 +1025,7 @@ extern "C" int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float
                                    const int32_t* flatten_ids, int64_t capacity, const float* render,
                                    const float* alphas, const int32_t* last_ids, const float* v_render,
                                    const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                   const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg,
+                                   const uint32_t* isect_hits, int long_min, void* long_ws, int max_seg,
                                    void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1 || long_min <= 0 || max_seg <= 0 || !long_ws)
@@ -1035,7 +1036,7 @@ extern "C" int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float
   if (!flatten_ids || (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2)))) return GSL_ERR_BAD_ARG;
   return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                    capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                   isect_hits, long_min, long_ws, max_seg, stream);
+                                   isect_hits, nullptr, long_min, long_ws, max_seg, stream);
 }
 
 extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,

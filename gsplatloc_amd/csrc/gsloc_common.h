@@ -295,6 +295,7 @@ struct LongWs {  // views into the caller's long_ws (sized by gsl_long_ws_bytes)
   int32_t* seg_tile;  // [max_seg]
   int32_t* seg_idx;   // [max_seg]  segment number inside its tile
   int32_t* seg_cnt;   // [max_seg]  segments of that tile
+  int32_t* seg_qcnt;  // [max_seg][4] length of the segment's hit list per quadrant (written by the forward's pass B)
   float* P;           // [max_seg][256]
   float* Tend;        // [max_seg][256]
   int32_t* last;      // [max_seg][256]
@@ -307,6 +308,7 @@ __host__ __device__ __forceinline__ LongWs long_ws_views(void* ws, int max_seg) 
   w.seg_tile = (int32_t*)p; p += (size_t)max_seg * 4;
   w.seg_idx = (int32_t*)p; p += (size_t)max_seg * 4;
   w.seg_cnt = (int32_t*)p; p += (size_t)max_seg * 4;
+  w.seg_qcnt = (int32_t*)p; p += (size_t)max_seg * 16;
   p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
   w.P = (float*)p; p += (size_t)max_seg * 256 * 4;
   w.Tend = (float*)p; p += (size_t)max_seg * 256 * 4;

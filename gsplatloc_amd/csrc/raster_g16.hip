@@ -123,7 +123,7 @@ __device__ __forceinline__ void qraster_bwd_body(
     QStage<D, CG>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
     const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, float* __restrict__ vacc, long long rs,
     long long re, int lane, int quad, float px, float py, float tx0, float ty0, int bin_final, float T_init,
-    float Bp_init, const float (&vc)[D], const uint16_t* __restrict__ isect_hits) {
+    float Bp_init, const float (&vc)[D], const uint32_t* __restrict__ qhits, int n_qhits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   constexpr int NV = QStage<D, CG>::NV;
@@ -160,24 +160,31 @@ __device__ __forceinline__ void qraster_bwd_body(
     sb.s1[GSL_QB] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (RGB && CG == D) sb.s2[GSL_QB] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  long long pos = re;  // entries [rs, pos) are still to be scanned, back to front
-  while (pos > rs) {
-    // ---- stage: scan chunks of 64 list entries until the batch is (nearly) full
+  // What is scanned, back to front, 64 per step: this quadrant's hit list from the forward (qhits: n_qhits entries of
+  // nibble << 28 | list index, every one of them relevant), or -- without it -- the tile's list itself, with the
+  // block tests done here.
+  long long pos = qhits ? (long long)n_qhits : re;
+  const long long pos_end = qhits ? 0 : rs;
+  while (pos > pos_end) {
+    // ---- stage: scan chunks of 64 until the batch is (nearly) full
     int staged = 0;
     int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
     __syncthreads();  // (one wave: orders the previous batch's LDS reads before these writes)
-    while (pos > rs && staged <= GSL_QB - 64) {
+    while (pos > pos_end && staged <= GSL_QB - 64) {
       long long idx = pos - 1 - lane;
-      bool in = idx >= rs;
+      bool in = idx >= pos_end;
       unsigned nib = 0;
       int gid = 0;
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
       if (in) {
-        gid = flatten_ids[idx];
-        if (isect_hits) {
-          nib = ((unsigned)isect_hits[idx] >> (4 * quad)) & 15u;
-          if (nib) load_record(Q0, Q1, Q2, Qh, gid, RGB && CG == D, r0, r1, r2);
+        if (qhits) {
+          unsigned e = qhits[idx];
+          nib = e >> 28;
+          idx = (long long)(e & 0x0FFFFFFFu);
+          gid = flatten_ids[idx];
+          load_record(Q0, Q1, Q2, Qh, gid, RGB && CG == D, r0, r1, r2);
         } else {
+          gid = flatten_ids[idx];
           load_record(Q0, Q1, Q2, Qh, gid, RGB && CG == D, r0, r1, r2);
           if (r1.w >= 0.f) {
             float rr = r1.w * r1.w;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
-    const uint16_t* __restrict__ isect_hits, int long_min, LongWs lw) {
+    const uint32_t* __restrict__ isect_hits, const int32_t* __restrict__ isect_hit_counts, int long_min, LongWs lw) {
   __shared__ QStage<D, CG> sb;
   const int quad = blockIdx.x & 3, item = blockIdx.x >> 2;
   int tile, sgm = 0, gseg = 0;
@@ -450,8 +457,24 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
       }
     }
   }
+  // this quadrant's hit list: at 4 x (start of the list or segment) + quadrant x its length
+  const uint32_t* qh = nullptr;
+  int nqh = 0;
+  if (isect_hits) {
+    long long ls = tile_offsets[tile], le = tile_offsets[tile + 1];
+    if (le > capacity) le = capacity;
+    if (LONG) {
+      ls += (long long)sgm * GSL_SEG;
+      le = min(ls + (long long)GSL_SEG, le);
+      nqh = lw.seg_qcnt[gseg * 4 + quad];
+    } else {
+      nqh = isect_hit_counts[tile * 4 + quad];
+    }
+    qh = isect_hits + 4 * ls + (long long)quad * (le - ls);
+    if (nqh == 0) return;
+  }
   qraster_bwd_body<D, CG>(sb, Q0, Q1, Q2, Qh, flatten_ids, vacc, rs, re, lane, quad, px, py, (float)(txi * 16),
-                          (float)(tyi * 16), bin_final, T_init, Bp_init, vc, isect_hits);
+                          (float)(tyi * 16), bin_final, T_init, Bp_init, vc, qh, nqh);
 }
 
 }  // namespace gsl
@@ -473,8 +496,8 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const int32_t* flatten_ids, int64_t capacity, const float* render,
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                                         const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg,
-                                         void* stream) {
+                                         const uint32_t* isect_hits, const int32_t* isect_hit_counts, int long_min,
+                                         void* long_ws, int max_seg, void* stream) {
   // long_ws == NULL: the tiles of the strip (those longer than long_min, if > 0, are skipped);
   // long_ws != NULL: only the (tile, segment) pairs the forward's long-list pass listed there
   hipStream_t st = (hipStream_t)stream;
@@ -487,12 +510,12 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
       hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, true>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, long_min, lw);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, isect_hit_counts, long_min, lw);                            \
     else                                                                                                     \
       hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, false>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, long_min, lw);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, isect_hit_counts, long_min, lw);                            \
   } while (0)
   if (channels == 1) { if (ed) CALL_Q(1, true, 1); else CALL_Q(1, false, 1); }
   else if (channels == 3) { CALL_Q(3, false, 3); }

@@ -32,7 +32,6 @@ struct PStage {
   float4 s2[(D >= 3) ? 256 : 1];
   uint16_t qlist[4][256];  // per-quadrant candidate slots, in list order
   int qcnt[4][4];          // [staging wave][quadrant]
-  uint8_t hit[4][256];     // [quadrant][batch slot]: which of the quadrant's four 4x4 blocks composited the entry
 };
 
 // Order-preserving compaction of the staged batch into per-quadrant candidate lists.
@@ -129,28 +128,20 @@ __device__ __forceinline__ void praster_walk(
     PStage<D>& sb, const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2,
     const uint4* __restrict__ Qh, const int32_t* __restrict__ flatten_ids, long long rs, long long re, int tid, float px,
     float py, int qx, int qy, int txi, int tyi, bool& done, float& T, float (&pix)[D], int& cur_idx,
-    uint16_t* __restrict__ isect_hits) {
+    uint32_t* __restrict__ isect_hits, int& n_hits) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   const int lane = tid & 63, wv = tid >> 6;
   int nb = (int)((re - rs + 255) / 256);
   if (MODE == 1) isect_hits = nullptr;
-  // isect_hits (may be NULL): per list entry, which of the tile's 16 blocks composited it on at least one pixel
-  // (bit 4 * quadrant + row): the compositing backward walks exactly those (block, entry) pairs
-  auto flush_hits = [&](int b) {  // after a barrier: every wave has finished batch b
-    long long bstart = rs + (long long)b * 256;
-    if (bstart + tid < re) {
-      unsigned h = (unsigned)sb.hit[0][tid] | ((unsigned)sb.hit[1][tid] << 4) | ((unsigned)sb.hit[2][tid] << 8) |
-                   ((unsigned)sb.hit[3][tid] << 12);
-      isect_hits[bstart + tid] = (uint16_t)h;
-    }
-  };
-  int b_done = -1;  // last batch whose hits are still in LDS
+  // isect_hits (may be NULL): this quadrant's HIT LIST -- the entries of [rs, re) that at least one of its pixels
+  // composited, in list order, each as (nibble of its four 4x4 blocks that did) << 28 | absolute list index, appended
+  // chunk by chunk at  isect_hits[4 rs + quadrant (re - rs) + n_hits ...]: the compositing backward walks exactly those
+  // (block, entry) pairs and never scans an entry its quadrant did not touch
+  uint32_t* const qout = isect_hits ? isect_hits + 4 * rs + (long long)wv * (re - rs) : nullptr;
+  n_hits = 0;
   for (int b = 0; b < nb; ++b) {
-    int all_done = __syncthreads_and(done);
-    if (isect_hits && b_done >= 0) flush_hits(b_done);
-    b_done = -1;
-    if (all_done) break;
+    if (__syncthreads_and(done)) break;
     long long bstart = rs + (long long)b * 256;
     int bsize = (int)min((long long)256, re - bstart);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
@@ -162,12 +153,7 @@ __device__ __forceinline__ void praster_walk(
       sb.s1[tid] = r1;
       if (RGB && MODE == 0) sb.s2[tid] = r2;
     }
-    if (isect_hits) {  // (the barrier inside compact_quadrants orders this after flush_hits' reads)
-      __syncthreads();
-      reinterpret_cast<unsigned*>(&sb.hit[0][0])[tid] = 0u;
-    }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
-    b_done = b;
     for (int c = 0; c < n; c += 64) {
       if (__all(done)) break;
       int e = c + lane;
@@ -256,13 +242,11 @@ __device__ __forceinline__ void praster_walk(
           unsigned long long gm = ((unsigned long long)ghi << 32) | glo;
           nib |= (unsigned)((gm >> lane) & 1ull) << g;
         }
-        if (nib) sb.hit[wv][sb.qlist[wv][e < n ? e : 0]] = (uint8_t)nib;  // (a set bit implies e < n)
+        unsigned long long Rm = __ballot(nib != 0);  // (a set bit implies e < n)
+        if (nib) qout[n_hits + __popcll(Rm & ((1ull << lane) - 1ull))] = (nib << 28) | (unsigned)((int)bstart + sb.qlist[wv][e]);
+        n_hits += __popcll(Rm);
       }
     }
-  }
-  if (isect_hits && b_done >= 0) {
-    __syncthreads();
-    flush_hits(b_done);
   }
 }
 
@@ -290,7 +274,8 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
     int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
-    int32_t* __restrict__ clear_state, uint16_t* __restrict__ isect_hits, int long_min) {
+    int32_t* __restrict__ clear_state, uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts,
+    int long_min) {
   __shared__ PStage<D> sb;
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
@@ -316,8 +301,10 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
   float pix[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) pix[k] = 0.f;
+  int n_hits = 0;
   praster_walk<D, 0>(sb, Q0, Q1, Q2, Qh, flatten_ids, rs, re, tid, px, py, tp.qx, tp.qy, tp.txi, tp.tyi, done, T, pix,
-                     cur_idx, isect_hits);
+                     cur_idx, isect_hits, n_hits);
+  if (isect_hits && (tid & 63) == 0) isect_hit_counts[tile * 4 + (tid >> 6)] = n_hits;
   if (inside) {
     size_t pid = (size_t)i * W + j;
     float A = 1.f - T;
@@ -399,7 +386,7 @@ template <int D, int PASS>
 __global__ __launch_bounds__(256) void k_long_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids, long long capacity,
-    int row0, int row1, const uint4* __restrict__ Qh, uint16_t* __restrict__ isect_hits, LongWs w) {
+    int row0, int row1, const uint4* __restrict__ Qh, uint32_t* __restrict__ isect_hits, LongWs w) {
   __shared__ PStage<D> sb;
   int g = blockIdx.x;
   if (g >= w.n_seg[0]) return;
@@ -420,8 +407,9 @@ __global__ __launch_bounds__(256) void k_long_fwd(
     float T = 1.f;
     int cur = 0;
     bool done = !inside;
+    int nh = 0;
     praster_walk<D, 1>(sb, Q0, Q1, Q2, Qh, flatten_ids, ss, se, tid, px, py, tp.qx, tp.qy, tp.txi, tp.tyi, done, T, pix,
-                       cur, nullptr);
+                       cur, nullptr, nh);
     w.P[slot] = T;
   } else {
     float T = 1.f;
@@ -429,8 +417,10 @@ __global__ __launch_bounds__(256) void k_long_fwd(
     bool dead = !inside || T <= GSL_T_STOP;  // stopped in an earlier segment
     bool done = dead;
     int cur = -1;
+    int nh = 0;  // the segment's hit lists sit at 4 ss + quadrant (se - ss), their lengths in the workspace
     praster_walk<D, 0>(sb, Q0, Q1, Q2, Qh, flatten_ids, ss, se, tid, px, py, tp.qx, tp.qy, tp.txi, tp.tyi, done, T, pix,
-                       cur, isect_hits);
+                       cur, isect_hits, nh);
+    if ((tid & 63) == 0) w.seg_qcnt[g * 4 + (tid >> 6)] = isect_hits ? nh : 0;
     // negative: the pixel stopped inside this segment (T is the value before the stop); 2: dead on arrival (a
     // transmittance is never 2), its T, index and partial are not this segment's to report
     w.Tend[slot] = dead ? 2.f : ((done && !dead) ? -T : T);
@@ -673,7 +663,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
                                  int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws,
-                                 uint16_t* isect_hits, int long_min, void* stream) {
+                                 uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -682,6 +672,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   if (capacity > 0 && !flatten_ids) return GSL_ERR_BAD_ARG;
   if (capacity > 0 && !Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  if (isect_hits && !isect_hit_counts) return GSL_ERR_BAD_ARG;
   if (ty0 == ty1) return GSL_OK;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
@@ -689,7 +680,8 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
-                     (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits, long_min)
+                     (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits,          \
+                     isect_hit_counts, long_min)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();
@@ -699,14 +691,14 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
 // ---- long tile lists (see the comment above k_long_map) ----------------------------------------------------------------
 extern "C" size_t gsl_long_ws_bytes(int max_seg) {
   if (max_seg <= 0) return 0;
-  size_t b = 16 + (size_t)3 * max_seg * 4 + 256;
+  size_t b = 16 + (size_t)(3 + 4) * max_seg * 4 + 256;
   return b + (size_t)max_seg * 256 * 4 * (1 + 1 + 1 + 4);
 }
 
 extern "C" int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                    int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                    const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
-                                   int32_t* last_ids, int row0, int row1, const void* Qh, uint16_t* isect_hits,
+                                   int32_t* last_ids, int row0, int row1, const void* Qh, uint32_t* isect_hits,
                                    int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1 || long_min <= 0 || max_seg <= 0)

@@ -76,14 +76,16 @@ class _FusedRasterization(torch.autograd.Function):
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, 1, dtype=f32, device=dev)
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
-        hits = torch.empty(cap, dtype=torch.int16, device=dev)  # blocks of its tile that composited each list entry
+        hits = torch.empty(4 * cap, dtype=torch.int32, device=dev)  # per tile and quadrant: the entries it composited
+        hit_counts = torch.empty(4 * n_tiles, dtype=i32, device=dev)
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
-                                       ptr(last_ids), 0, H, None, None, ptr(hits), 0, st), "gsl_fused_raster_fwd")
+                                       ptr(last_ids), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, st),
+              "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
                               comps if antialiased else torch.empty(0, device=dev), offs, flatten_ids, render,
-                              alphas, last_ids, ws, hits)
+                              alphas, last_ids, ws, hits, hit_counts)
         ctx.cfg = cfg
         ctx.n_isects = n_isects
         ctx.K_sh = K_sh
@@ -98,7 +100,7 @@ class _FusedRasterization(torch.autograd.Function):
     def backward(ctx, v_render, v_alphas, _v_last):
         lib = load_library()
         (means, quats, scales, opacities, colors, viewmat, K, radii, Q0, Q1, Q2, comps, offs, flatten_ids, render,
-         alphas, last_ids, ws, hits) = ctx.saved_tensors
+         alphas, last_ids, ws, hits, hit_counts) = ctx.saved_tensors
         (W, H, sh_degree, mode, eps2d, near, far, radius_clip, antialiased, ty0, ty1, _) = ctx.cfg
         D, ed = _MODES[mode]
         rgb = D >= 3
@@ -115,7 +117,8 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(vacc), 0, H, None, None, ptr(hits), 0, st), "gsl_fused_raster_bwd")
+                                       ptr(vacc), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, st),
+              "gsl_fused_raster_bwd")
         ni = ctx.needs_input_grad
         full = any(ni[:5])
         v_means = v_quats = v_scales = v_opac = v_colors = None

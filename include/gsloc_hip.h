@@ -156,11 +156,15 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     Forward: every lane walks the candidate list of its own pixel (csrc/raster_px.hip);
  *                     backward: each 16-lane DPP row of a wave walks the list of its own 4x4 pixel block
  *                     (csrc/raster_g16.hip; deterministic mode: quadrant walk with per-splat pixel sums on the
- *                     matrix cores, v_mfma_f32_16x16x4_f32, exact f32, csrc/fused.hip).  isect_hits (uint16 per
- *                     intersection, may be NULL in both calls): the forward records for every list entry which of
- *                     the tile's 16 blocks composited it on at least one pixel (bit 4 * quadrant + row), and the
- *                     backward given the same array walks exactly those (block, entry) pairs instead of testing the
- *                     splat's alpha >= 1/255 disc against the blocks.  Only pixel rows [row0,row1)
+ *                     matrix cores, v_mfma_f32_16x16x4_f32, exact f32, csrc/fused.hip).  isect_hits (uint32[4 x capacity])
+ *                     + isect_hit_counts (int32[4 x n_tiles]), may be NULL together in both calls: the forward leaves, per
+ *                     tile and 8x8 quadrant, the list of the entries at least one of the quadrant's pixels composited --
+ *                     (nibble of its four 4x4 blocks that did) << 28 | list index, in list order, at
+ *                     isect_hits[4 start + quadrant x length ...] for the tile's list [start, start + length), its
+ *                     length in isect_hit_counts[4 tile + quadrant] -- and the backward given the same arrays walks
+ *                     exactly those (block, entry) pairs instead of scanning the tile's list and testing every splat's
+ *                     alpha >= 1/255 disc against the blocks.  (Segments of long lists: same layout per segment, the
+ *                     lengths live in long_ws.)  Only pixel rows [row0,row1)
  *                     of the tile rows [ty0,ty1) are rendered / back-propagated (whole strip: 0,height):
  *                     a strip's one-pixel Sobel halo costs one pixel row, not a tile row.
  * fp16 staging (Qh, may be NULL everywhere): gsl_fused_project additionally packs one 32-byte record per Gaussian
@@ -218,13 +222,15 @@ int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int 
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
-                         void* binned_ws, uint16_t* isect_hits, int long_min, void* stream);
+                         void* binned_ws, uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min,
+                         void* stream);
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
-                         const void* Qh, float* vrow, const uint16_t* isect_hits, int long_min, void* stream);
+                         const void* Qh, float* vrow, const uint32_t* isect_hits,
+                         const int32_t* isect_hit_counts, int long_min, void* stream);
 /* Long tile lists split over workgroups (long_min > 0 in the calls above and in gsl_tiny_raster_bwd: tiles whose list
  * is longer than long_min entries are skipped there and handled here).  A pile of splats in one tile -- the invalid
  * pixels of a TUM depth frame, /root/reference/src/data/Image.py:29-35 -- is cut into segments of 512 entries, one
@@ -238,14 +244,14 @@ size_t gsl_long_ws_bytes(int max_seg);
 int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                         int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                         const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
-                        int32_t* last_ids, int row0, int row1, const void* Qh, uint16_t* isect_hits,
+                        int32_t* last_ids, int row0, int row1, const void* Qh, uint32_t* isect_hits,
                         int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, void* stream);
 int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                         int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                         const int32_t* flatten_ids, int64_t capacity, const float* render,
                         const float* alphas, const int32_t* last_ids, const float* v_render,
                         const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
-                        const uint16_t* isect_hits, int long_min, void* long_ws, int max_seg, void* stream);
+                        const uint32_t* isect_hits, int long_min, void* long_ws, int max_seg, void* stream);
 int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,
                           const float* opacities, const float* colors, int sh_degree, int K_sh,
                           const float* viewmat, const float* K, int N, int width, int height,

@@ -14,7 +14,7 @@ GUARD = 64 * 1024
 CANARY = 0xA5
 
 WRITABLE = ["radii", "Q0", "Q1", "Q2", "comps", "offs", "n_is", "ws", "render", "alphas", "last_ids", "vacc",
-            "v_viewmat", "v_means", "v_quats", "v_scales", "v_opacities", "v_colors", "keys", "flatten_ids", "hits", "trec",
+            "v_viewmat", "v_means", "v_quats", "v_scales", "v_opacities", "v_colors", "keys", "flatten_ids", "hits", "hit_counts", "trec",
             "vcT", "long_ws"]
 
 
