@@ -39,7 +39,8 @@ _SIGNATURES = {
                                   c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t,
                                   P, P, c_int, P, P]),
     "gsl_fused_bin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P, P, P, P, c_size_t, c_int,
-                              P, c_int, P, P, P]),
+                              P, c_int, P, P, c_int, P]),
+    "gsl_long_sort": (c_int, [P, c_int, c_int, c_int, c_int, c_int64, P, c_int, P, P, c_int, P, c_size_t, c_int, c_int, P]),
     "gsl_fused_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                      P, P, P, c_int, c_int, P, P, P, P, c_int, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,

@@ -105,7 +105,7 @@ class RenderContext:
         self._counters_dirty = False
         self.trec = self.vcT = None
         # long tile lists (a pile of splats in one tile): split over workgroups when calibrate() finds one
-        self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes = 0, 0, None, 0
+        self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes, self.long_passes = 0, 0, None, 0, 0
         self.keys = self.flatten_ids = self.hits = None
         if capacity is not None:
             self._alloc_isects(int(capacity))
@@ -137,7 +137,7 @@ class RenderContext:
     def _alloc_long(self, sizes: Tensor, headroom: float) -> None:
         """Long-list mode: on when some tile list comes near LONG_MIN entries (deterministic mode keeps its own
         backward).  The workspace holds headroom x the segments of every tile that is at least half that long."""
-        self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes = 0, 0, None, 0
+        self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes, self.long_passes = 0, 0, None, 0, 0
         if self.deterministic or os.environ.get("GSLOC_LONG_LISTS", "1") == "0" or not sizes.numel():
             return
         # "long" is relative to the frame: four times its mean (non-empty) list, at least LONG_MIN entries -- workload X
@@ -150,12 +150,17 @@ class RenderContext:
             return
         segs = int(torch.ceil(near.double() * max(headroom, 1.5) / 512.0).sum()) + 8
         self.long_min, self.max_seg = long_min, segs
+        # merge passes of the long-list sort: runs of 512 keys doubled until they cover 1.5 x the longest list
+        import math
+        self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * float(near.max()) / 512.0))))
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
     def grow_long(self, needed: int) -> None:
         """Recovery after long_overflowed(): a workspace for 1.5 x the segments the frame needed."""
-        self.long_min, self.max_seg = max(self.long_min, LONG_MIN), int(needed * 1.5) + 8
+        import math
+        self.long_min, self.max_seg = max(self.long_min, LONG_MIN), max(self.max_seg, int(needed * 1.5) + 8)
+        self.long_passes = max(self.long_passes, math.ceil(math.log2(max(2.0, 1.5 * needed))))
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(self.max_seg)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
@@ -163,7 +168,8 @@ class RenderContext:
         """Host sync: 0, or the number of (tile, segment) pairs a frame needed beyond the long-list workspace."""
         if self.long_ws is None:
             return 0
-        return int(self.long_ws[:16].view(torch.int32)[1].item())
+        st = self.long_ws[:16].view(torch.int32).tolist()
+        return int(st[1]) if st[1] else (int(st[2]) // 512 + 1 if st[2] else 0)
 
     def _alloc_bins(self, bin_cap: int) -> None:
         """Fixed-capacity per-tile key bins: the projection kernel then bins directly (no scatter pass, no counter
@@ -257,8 +263,14 @@ class RenderContext:
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
                                      ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, int(self.deterministic),
-                                     ptr(self.bins), self.bin_cap, ptr(self.n_is), ptr(self.flags), current_stream()),
+                                     ptr(self.bins), self.bin_cap, ptr(self.n_is), ptr(self.flags),
+                                     self.long_min if self.bins is not None else 0, current_stream()),
               "gsl_fused_bin")
+        if self.long_min and self.bins is not None:  # the long lists: sorted by several workgroups
+            check(self.lib.gsl_long_sort(ptr(self.offs), self.tw, self.th, self.ty0, self.ty1, self.capacity,
+                                         ptr(self.bins), self.bin_cap, ptr(self.keys), ptr(self.flatten_ids),
+                                         self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
+                                         self.long_passes, current_stream()), "gsl_long_sort")
 
     def _raster_fwd(self) -> None:
         check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,

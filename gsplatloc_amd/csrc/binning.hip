@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
                                                    int64_t* __restrict__ isect_ids, int64_t cam_enc,
                                                    int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap,
                                                    const int32_t* __restrict__ counts, int32_t* __restrict__ n_isects,
-                                                   int32_t* __restrict__ flags) {
+                                                   int32_t* __restrict__ flags, int long_min) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
   __shared__ int s_scan[8];
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
     int n = (int)max(e - s, (long long)0);
     if (bins && n > bin_cap) n = bin_cap;
     if (n <= GSL_SORT_WAVE_MAX) continue;
+    if (long_min > 0 && bins && n > long_min) continue;  // sorted by several workgroups: gsl_long_sort
     uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
     __syncthreads();
     bitonic_sort_long(src, n, skeys, tid);
@@ -584,6 +585,97 @@ __global__ __launch_bounds__(256) void k_isect_offsets(const int64_t* __restrict
     int64_t pid = isect_ids[idx - 1];
     long long prev = (pid >> (32 + tile_n_bits)) * n_tiles + ((pid >> 32) & mask);
     for (long long q = prev + 1; q <= cur; ++q) offsets[q] = (int32_t)idx;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Sort of a LONG tile list by several workgroups (binned mode).  One workgroup sorted such a list block-wise in 1.6 ms
+// (23 k keys: the pile of invalid TUM points) -- after the compositing of that list had been split
+// over workgroups it was three quarters of the iteration.  Now: every 512-key segment of the list is sorted in
+// registers by one wave (k_long_sort_seg, into the packed key array), then `passes` merge passes double the run length,
+// one wave per 512 outputs (merge path: the two diagonals of the chunk are located by binary search in the two runs,
+// the <= 512 inputs staged in LDS, every lane merges its 8 outputs), ping-ponging between the packed key array and the
+// tile's bin; the last pass writes flatten_ids.  Same result as any stable sort of the (depth bits, id) keys.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_long_sort_seg(const int32_t* __restrict__ tile_offsets, long long capacity,
+                                                      const uint64_t* __restrict__ bins, int bin_cap,
+                                                      uint64_t* __restrict__ keys, LongWs w) {
+  int g = blockIdx.x;
+  if (g >= w.n_seg[0]) return;
+  int tile = w.seg_tile[g], sgm = w.seg_idx[g];
+  long long s = tile_offsets[tile], e = tile_offsets[tile + 1];
+  if (e > capacity) e = capacity;
+  int n = (int)min((long long)bin_cap, e - s);
+  int lane = threadIdx.x;
+  const uint64_t* src = bins + (size_t)tile * (size_t)bin_cap + (size_t)sgm * GSL_SEG;
+  int m = min(GSL_SEG, n - sgm * GSL_SEG);
+  uint64_t k[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) k[r] = (lane * 8 + r < m) ? src[lane * 8 + r] : ~0ull;
+  wave_sort_regs<3>(k, lane);
+  uint64_t* dst = keys + s + (size_t)sgm * GSL_SEG;
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (lane * 8 + r < m) dst[lane * 8 + r] = k[r];
+}
+
+// smallest ia in [lo, hi] such that the first d merged elements take ia from A (keys are unique)
+__device__ __forceinline__ int merge_diag(const uint64_t* __restrict__ A, int lenA, const uint64_t* __restrict__ B, int lenB,
+                                          int d) {
+  int lo = max(0, d - lenB), hi = min(d, lenA);
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (A[mid] <= B[d - 1 - mid]) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// pass p: runs of (GSL_SEG << p) keys -> runs of twice that.  src / dst: the packed key array and the bins, alternating.
+__global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ tile_offsets, long long capacity,
+                                                   uint64_t* __restrict__ bins, int bin_cap, uint64_t* __restrict__ keys,
+                                                   int pass, int last, int32_t* __restrict__ flatten_ids, LongWs w) {
+  __shared__ uint64_t sk[GSL_SEG];
+  __shared__ int s_split[4];
+  int g = blockIdx.x;
+  if (g >= w.n_seg[0]) return;
+  int tile = w.seg_tile[g], sgm = w.seg_idx[g];
+  long long s = tile_offsets[tile], e = tile_offsets[tile + 1];
+  if (e > capacity) e = capacity;
+  int n = (int)min((long long)bin_cap, e - s);
+  int lane = threadIdx.x;
+  uint64_t* kbase = keys + s;
+  uint64_t* bbase = bins + (size_t)tile * (size_t)bin_cap;
+  const uint64_t* src = (pass & 1) ? bbase : kbase;
+  uint64_t* dst = (pass & 1) ? kbase : bbase;
+  int L = GSL_SEG << pass;
+  int pair_start = (sgm * GSL_SEG) / (2 * L) * (2 * L);
+  int o = sgm * GSL_SEG - pair_start;
+  int lenA = max(0, min(L, n - pair_start)), lenB = max(0, min(L, n - pair_start - L));
+  int out_len = min(GSL_SEG, lenA + lenB - o);
+  const uint64_t* A = src + pair_start;
+  const uint64_t* B = src + pair_start + L;
+  if (lane < 2) {
+    int d = lane == 0 ? o : o + out_len;
+    int ia = merge_diag(A, lenA, B, lenB, d);
+    s_split[2 * lane] = ia;
+    s_split[2 * lane + 1] = d - ia;
+  }
+  __syncthreads();
+  int ia0 = s_split[0], ib0 = s_split[1], na = s_split[2] - ia0, nb = s_split[3] - ib0;
+  for (int q = lane; q < na; q += 64) sk[q] = A[ia0 + q];
+  for (int q = lane; q < nb; q += 64) sk[na + q] = B[ib0 + q];
+  __syncthreads();
+  // every lane merges its 8 outputs from the staged pieces
+  int d0 = min(lane * 8, out_len), d1 = min(lane * 8 + 8, out_len);
+  int ia = merge_diag(sk, na, sk + na, nb, d0), ib = d0 - ia;
+  for (int d = d0; d < d1; ++d) {
+    uint64_t v;
+    if (ib >= nb || (ia < na && sk[ia] <= sk[na + ib])) v = sk[ia++];
+    else v = sk[na + ib++];
+    dst[pair_start + o + d] = v;
+    if (last) flatten_ids[s + pair_start + o + d] = (int32_t)(uint32_t)v;
   }
 }
 
@@ -659,7 +751,7 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      const_cast<int32_t*>(tile_offsets), tile_begin, n_strip_tiles, (long long)capacity, sort_keys,
-                     flatten_ids, isect_ids, cam_enc, 0, (uint64_t*)nullptr, 0, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+                     flatten_ids, isect_ids, cam_enc, 0, (uint64_t*)nullptr, 0, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 0);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -669,14 +761,14 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
 extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                                   int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
-                                  int32_t* n_isects, int32_t* flags, void* stream) {
+                                  int32_t* n_isects, int32_t* flags, int long_min, void* stream) {
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (counts && (!bins || tile_begin != 0)) return GSL_ERR_BAD_ARG;  // the scan runs over all tiles, bins only
   if (n_strip_tiles == 0 || (capacity == 0 && !counts)) return GSL_OK;
   if (capacity > 0 && (!sort_keys || !flatten_ids)) return GSL_ERR_BAD_ARG;
   hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
                      tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
-                     write_sorted_keys, bins, bin_cap, counts, n_isects, flags);
+                     write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -702,6 +794,29 @@ extern "C" int gsl_isect_offsets(const int64_t* isect_ids, int64_t n_isects, int
   long long work = n_isects > 0 ? (long long)n_isects : (long long)n_cameras * n_tiles;
   hipLaunchKernelGGL(gsl::k_isect_offsets, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      isect_ids, (long long)n_isects, n_cameras, n_tiles, tile_n_bits, offsets);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}
+
+// Multi-workgroup sort of the long tile lists (binned mode; see k_long_sort_seg).  Call after gsl_fused_bin(long_min).
+extern "C" int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
+                             uint64_t* bins, int bin_cap, uint64_t* sort_keys, int32_t* flatten_ids, int long_min,
+                             void* long_ws, size_t long_ws_bytes, int max_seg, int passes, void* stream) {
+  if (tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0 || long_min <= 0 ||
+      max_seg <= 0 || passes < 0 || passes > 12 || bin_cap <= 0)
+    return GSL_ERR_BAD_ARG;
+  if (!tile_offsets || !bins || !sort_keys || !flatten_ids || !long_ws) return GSL_ERR_BAD_ARG;
+  if (long_ws_bytes < gsl_long_ws_bytes(max_seg)) return GSL_ERR_WORKSPACE;
+  if (ty0 == ty1 || capacity == 0) return GSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  gsl::LongWs w = gsl::long_ws_views(long_ws, max_seg);
+  hipLaunchKernelGGL(gsl::k_long_map, dim3(1), dim3(1024), 0, st, tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w,
+                     (long long)capacity, long_min, max_seg, GSL_SEG << passes, w);
+  hipLaunchKernelGGL(gsl::k_long_sort_seg, dim3(max_seg), dim3(64), 0, st, tile_offsets, (long long)capacity, bins,
+                     bin_cap, sort_keys, w);
+  for (int p = 0; p < passes; ++p)
+    hipLaunchKernelGGL(gsl::k_long_merge, dim3(max_seg), dim3(64), 0, st, tile_offsets, (long long)capacity, bins, bin_cap,
+                       sort_keys, p, p == passes - 1 ? 1 : 0, flatten_ids, w);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

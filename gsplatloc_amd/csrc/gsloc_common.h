@@ -317,6 +317,53 @@ __host__ __device__ __forceinline__ LongWs long_ws_views(void* ws, int max_seg) 
   return w;
 }
 
+// One workgroup: the (tile, segment) pairs of every tile of the strip whose list is longer than long_min.
+static __global__ __launch_bounds__(1024) void k_long_map(const int32_t* __restrict__ tile_offsets, int tile_begin, int n_strip_tiles,
+                                                   long long capacity, int long_min, int max_seg, int max_list, LongWs w) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_strip_tiles; base += 1024) {
+    int q = base + tid;
+    int nseg = 0, tile = tile_begin + q;
+    if (q < n_strip_tiles) {
+      long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
+      if (re > capacity) re = capacity;
+      long long len = re - rs;
+      if (len > long_min) nseg = (int)((len + GSL_SEG - 1) / GSL_SEG);
+      if (max_list > 0 && len > long_min && len > max_list) w.n_seg[2] = (int)len;  // longer than the merge passes cover
+    }
+    int x = nseg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wv] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    int first = carry_s + woff + x - nseg;
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+      int g = first + sgm;
+      if (g < max_seg) {
+        w.seg_tile[g] = tile;
+        w.seg_idx[g] = sgm;
+        w.seg_cnt[g] = nseg;
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry_s + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    w.n_seg[0] = min(carry_s, max_seg);
+    if (carry_s > max_seg) w.n_seg[1] = carry_s;  // sticky: more segments than the workspace holds (host polls)
+  }
+}
+
 // Tile rectangle of a projected Gaussian: [xmin,xmax) x [ymin,ymax) in tiles.
 __device__ __forceinline__ void tile_rect(float mx, float my, int radius, int tile_size, int tile_w,
                                           int tile_h, int& xmin, int& ymin, int& xmax, int& ymax) {

@@ -336,52 +336,6 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
 // product changes ((P_0 P_1) x ... instead of one running product), a last-bit effect.  The backward
 // (raster_g16.hip, k_long_bwd) restarts each segment from the stored T and the colour partials of the later segments.
 // ---------------------------------------------------------------------------------------------------
-// One workgroup: the (tile, segment) pairs of every tile of the strip whose list is longer than long_min.
-__global__ __launch_bounds__(1024) void k_long_map(const int32_t* __restrict__ tile_offsets, int tile_begin, int n_strip_tiles,
-                                                   long long capacity, int long_min, int max_seg, LongWs w) {
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n_strip_tiles; base += 1024) {
-    int q = base + tid;
-    int nseg = 0, tile = tile_begin + q;
-    if (q < n_strip_tiles) {
-      long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-      if (re > capacity) re = capacity;
-      long long len = re - rs;
-      if (len > long_min) nseg = (int)((len + GSL_SEG - 1) / GSL_SEG);
-    }
-    int x = nseg;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      int y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum[wv] = x;
-    __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < wv; ++k) woff += wsum[k];
-    int first = carry_s + woff + x - nseg;
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-      int g = first + sgm;
-      if (g < max_seg) {
-        w.seg_tile[g] = tile;
-        w.seg_idx[g] = sgm;
-        w.seg_cnt[g] = nseg;
-      }
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = carry_s + woff + x;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    w.n_seg[0] = min(carry_s, max_seg);
-    if (carry_s > max_seg) w.n_seg[1] = carry_s;  // sticky: more segments than the workspace holds (host polls)
-  }
-}
-
 template <int D, int PASS>
 __global__ __launch_bounds__(256) void k_long_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
@@ -711,7 +665,7 @@ extern "C" int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float
   hipStream_t st = (hipStream_t)stream;
   gsl::LongWs w = gsl::long_ws_views(long_ws, max_seg);
   hipLaunchKernelGGL(gsl::k_long_map, dim3(1), dim3(1024), 0, st, tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w,
-                     (long long)capacity, long_min, max_seg, w);
+                     (long long)capacity, long_min, max_seg, 0, w);
   GSL_CHECK_LAUNCH();
 #define CALL_LF(DD, EE)                                                                                          \
   do {                                                                                                           \

@@ -70,7 +70,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_bin(ptr(Q0), ptr(radii), N, tw, th, ty0, ty1, tile_n_bits(n_tiles), ptr(offs), n_isects,
                                 ptr(keys), ptr(flatten_ids) if n_isects else None,
                                 ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, 0, None, 0,
-                                None, None, st), "gsl_fused_bin")
+                                None, None, 0, st), "gsl_fused_bin")
         render = torch.zeros(H, W, D, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, D, dtype=f32, device=dev)
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \

@@ -217,7 +217,7 @@ int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int 
                   int ty1, int tile_n_bits, int32_t* tile_offsets, int64_t capacity,
                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
                   size_t ws_bytes, int write_sorted_keys, void* bins, int bin_cap, int32_t* n_isects,
-                  int32_t* flags, void* stream);
+                  int32_t* flags, int long_min, void* stream);
 int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
@@ -241,6 +241,13 @@ int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int 
  * gsl_long_raster_fwd after gsl_fused_raster_fwd, gsl_long_raster_bwd after gsl_fused_raster_bwd / gsl_tiny_raster_bwd
  * (it adds into vacc; gsl_fused_project_bwd given both tiny_trec and vacc consumes both). */
 size_t gsl_long_ws_bytes(int max_seg);
+/* Binned mode only: gsl_fused_bin(long_min > 0) leaves the lists longer than long_min unsorted, and gsl_long_sort (call it
+ * right after) sorts them with one wave per 512-key segment (registers) + `passes` merge-path passes (2^passes segments per
+ * list at most; a longer list sets long_ws[2] (int32)), ping-ponging between sort_keys (scratch, packed) and the tile's
+ * bin; flatten_ids receives the result.  One workgroup used to take 1.6 ms for a 23 k-entry list. */
+int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
+                  uint64_t* bins, int bin_cap, uint64_t* sort_keys, int32_t* flatten_ids, int long_min,
+                  void* long_ws, size_t long_ws_bytes, int max_seg, int passes, void* stream);
 int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                         int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                         const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
