@@ -772,3 +772,90 @@ def test_wide_features_are_composited_in_channel_chunks():
         assert rg.shape == (1, H, W, Dc + 1)
         mostly_close(rg, ro, rtol=1e-4, atol=2e-5, max_bad_frac=2e-3, what=f"33 channels, chunk {chunk}")
         mostly_close(ag, ao, rtol=1e-4, atol=2e-5, max_bad_frac=2e-3, what=f"alpha, chunk {chunk}")
+
+
+def test_backward_without_the_forwards_hit_lists_matches_the_one_with():
+    """The compositing backward walks the (block, entry) pairs the forward recorded (isect_hits); given NULL it scans
+    the tile lists itself and tests every splat's alpha >= 1/255 disc against its quadrant's blocks.  Same gradients
+    (the geometric test only adds pairs in which no pixel passes the alpha test)."""
+    _gpu()
+    from gsplatloc_amd.context import RenderContext
+    W, H, N = 250, 190, 30000
+    for sigma_px, aniso in ((1.3, False), (2.5, True)):
+        sc = random_scene(N, W, H, seed=21, sigma_px=sigma_px, aniso=aniso, opacity=(0.3, 1.0), dtype=torch.float32)
+        sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+        ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
+        V = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
+        K = sc["K"].to(DEV).contiguous()
+        v = torch.randn(H, W, 4, generator=torch.Generator().manual_seed(2)).to(DEV)
+        va = torch.randn(H, W, 1, generator=torch.Generator().manual_seed(3)).to(DEV)
+        rc = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV)
+        rc.calibrate(*ins, V, K)
+        assert not rc.tiny
+        rc.forward(*ins, V, K)
+        a = {k: t.clone() for k, t in rc.backward(v, va).items()}
+        keep = (rc.hits, rc.hit_counts)
+        rc.hits = rc.hit_counts = None
+        rc.forward(*ins, V, K)
+        b = {k: t.clone() for k, t in rc.backward(v, va).items()}
+        rc.hits, rc.hit_counts = keep
+        rc.check_capacity()
+        for k in ("viewmat", "means", "scales", "opacities", "colors"):
+            assert rel_inf(b[k], a[k]) < 2e-5, (sigma_px, k, rel_inf(b[k], a[k]))
+
+
+def test_cached_drop_in_call_recomputes_recalibrates_and_owns_its_outputs():
+    """gsplat.rasterization keeps one RenderContext per call signature (fused.py).  The cases the reference's loop never
+    produces but a drop-in must survive: (1) two forwards before the first one's backward (the node re-runs its own
+    forward); (2) a scene that outgrows the buffers measured on the first call (re-measured, the call repeated);
+    (3) outputs and gradients are fresh tensors (a later call does not change an earlier result); all against the
+    allocate-per-call path."""
+    _gpu()
+    import os
+
+    import gsplatloc_amd as A
+    from gsplatloc_amd.fused import clear_context_cache
+
+    W, H, N = 200, 150, 6000
+    sc = random_scene(N, W, H, seed=31, sigma_px=1.5, opacity=(0.3, 1.0), dtype=torch.float32)
+    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+    base = dict(quats=sc["quats"].to(DEV), opacities=sc["opacities"].to(DEV), colors=sh, Ks=sc["K"][None].to(DEV), width=W,
+                height=H, sh_degree=1, render_mode="RGB+ED")
+    means, scales = sc["means"].to(DEV), sc["scales"].to(DEV)
+    Va = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV)
+    Vb = torch.linalg.inv(small_pose(1.5, 0.05, dtype=torch.float32)).to(DEV)
+
+    def call(V, scale_factor=1.0, cached=True):
+        os.environ["GSLOC_DROPIN_CACHE"] = "1" if cached else "0"
+        try:
+            Vg = V.clone().requires_grad_()
+            m = means.clone().requires_grad_()
+            r, a, _ = A.rasterization(means=m, scales=scales * scale_factor, viewmats=Vg[None], **base)
+            return r, a, Vg, m
+        finally:
+            os.environ.pop("GSLOC_DROPIN_CACHE", None)
+
+    w = torch.linspace(0.5, 1.5, H * W * 4, device=DEV).reshape(1, H, W, 4)
+    clear_context_cache()
+    # reference results, allocate-per-call
+    ref = {}
+    for name, V, sf in (("a", Va, 1.0), ("b", Vb, 1.0), ("big", Va, 4.0)):
+        r, a, Vg, m = call(V, sf, cached=False)
+        (r * w).sum().backward()
+        ref[name] = (r.detach().clone(), Vg.grad.clone(), m.grad.clone())
+    # (1) + (3): forward a, forward b, THEN backward a, then backward b
+    ra, aa, Vga, ma = call(Va)
+    ra_copy = ra.detach().clone()
+    rb, ab, Vgb, mb = call(Vb)
+    assert torch.equal(ra.detach(), ra_copy), "a later call overwrote an earlier call's output"
+    (ra * w).sum().backward()
+    (rb * w).sum().backward()
+    for got, want in (((ra, Vga, ma), ref["a"]), ((rb, Vgb, mb), ref["b"])):
+        assert torch.equal(got[0].detach(), want[0])  # same kernels, same lists: bit-identical images
+        assert rel_inf(got[1].grad, want[1]) < 1e-5 and rel_inf(got[2].grad, want[2]) < 1e-5
+    # (2) four times larger splats: ~16 x the intersections of the calibration call
+    rg, ag, Vgg, mg = call(Va, 4.0)
+    (rg * w).sum().backward()
+    assert torch.equal(rg.detach(), ref["big"][0])
+    assert rel_inf(Vgg.grad, ref["big"][1]) < 1e-5 and rel_inf(mg.grad, ref["big"][2]) < 1e-5
+    clear_context_cache()
