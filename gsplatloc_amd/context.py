@@ -100,9 +100,12 @@ class RenderContext:
         self.flags = self.status[0:4]
         self.last_n_isects = 0
         self.tiles_per_gauss = None  # optional [N] int32 output of the projection (gsplat's meta key)
+        self.record_hits = True  # False: a forward nobody will back-propagate skips the hit lists (and its backward, if
+        # one is asked for after all, tests the blocks geometrically: same result)
         self.generation = 0  # counts forwards: an autograd node checks that "its" forward is still the last one
         self.bins, self.bin_cap = None, 0
         self._counters_dirty = False
+        self._hits_valid = False
         self.trec = self.vcT = None
         # long tile lists (a pile of splats in one tile): split over workgroups when calibrate() finds one
         self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes, self.long_passes = 0, 0, None, 0, 0
@@ -277,15 +280,19 @@ class RenderContext:
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
-                                            ptr(self.ws) if self.bins is not None else None, ptr(self.hits),
-                                            ptr(self.hit_counts), self.long_min, current_stream()),
+                                            ptr(self.ws) if self.bins is not None else None,
+                                            ptr(self.hits) if self.record_hits else None,
+                                            ptr(self.hit_counts) if self.record_hits else None, self.long_min,
+                                            current_stream()),
               "gsl_fused_raster_fwd")
         self._counters_dirty = False
+        self._hits_valid = self.record_hits and self.hits is not None
         if self.long_min:
             check(self.lib.gsl_long_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
                                                self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                                ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
-                                               ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh), ptr(self.hits),
+                                               ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
+                                               ptr(self.hits) if self.record_hits else None,
                                                self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
                                                current_stream()), "gsl_long_raster_fwd")
 
@@ -299,11 +306,13 @@ class RenderContext:
             # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
-                                                ptr(self.vrow), ptr(self.hits), ptr(self.hit_counts), self.long_min,
+                                                ptr(self.vrow), ptr(self.hits) if self._hits_valid else None,
+                                                ptr(self.hit_counts) if self._hits_valid else None, self.long_min,
                                                 current_stream()),
                   "gsl_fused_raster_bwd")
         if self.long_min:  # the segments of the long tiles: rows added to vacc
-            check(self.lib.gsl_long_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh), ptr(self.hits),
+            check(self.lib.gsl_long_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
+                                               ptr(self.hits) if self._hits_valid else None,
                                                self.long_min, ptr(self.long_ws), self.max_seg, current_stream()),
                   "gsl_long_raster_bwd")
 

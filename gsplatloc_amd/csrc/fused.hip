@@ -853,6 +853,35 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
 
 // Fixed-order sum of the partial rows, chain of the SH view direction through the camera
 // position (campos = -R^-1 t), result into v_viewmat[16] (row 3 = 0: that row is constant).
+// Stage 1 for many rows (N > 1 M: one workgroup summing 19 532 rows took 41 us at workload X): 64 workgroups each add
+// up a contiguous span of rows (same thread layout as reduce_viewmat_rows: thread = (row mod 64, quarter), fixed order)
+// into one row of `out`; k_freduce_viewmat then sums those 64.
+__global__ __launch_bounds__(256) void k_freduce_rows(const float* __restrict__ partials, int nb, float* __restrict__ out) {
+  __shared__ float red[4][16];
+  int span = (nb + (int)gridDim.x - 1) / (int)gridDim.x;
+  int r0 = blockIdx.x * span, r1 = min(nb, r0 + span);
+  int q = threadIdx.x & 3;
+  const float4* rows = reinterpret_cast<const float4*>(partials) + q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = r0 + (threadIdx.x >> 2); b < r1; b += 64) {
+    float4 x = rows[(size_t)b * 4];
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+  }
+  float v4[4] = {a.x, a.y, a.z, a.w};
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = v4[c];
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+    if (lane < 4) red[wv][4 * q + c] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16)
+    out[(size_t)blockIdx.x * 16 + threadIdx.x] =
+        threadIdx.x < 15 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict__ partials, int nb,
                                                         const float* __restrict__ V, const float* __restrict__ Kmat,
                                                         float* __restrict__ v_viewmat) {
@@ -866,6 +895,7 @@ __global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------- C ABI
 // ws = [tile_counts n_tiles][cursors n_tiles][pad to 16 bytes][pose-gradient rows ceil(N/256) x 16 floats]
+#define GSL_VM_STAGE_ROWS 64  // scratch rows behind the ceil(N / 256) pose-gradient rows: stage 1 of the row reduction
 static inline size_t gsl_vm_rows_offset(int n_tiles) { return ((size_t)2 * (size_t)n_tiles * sizeof(int32_t) + 15) & ~(size_t)15; }
 
 // state word of the binned mode's counter contract: the 16th float of the first pose-gradient row (rows use 15)
@@ -875,7 +905,7 @@ extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles) { return (ws && n
 extern "C" size_t gsl_fused_ws_bytes(int N, int n_tiles) {
   // [tile_counts n_tiles][cursors n_tiles][partials ceil(N/256)*16 floats]
   size_t nb = ((size_t)(N > 0 ? N : 1) + 255) / 256;
-  return gsl_vm_rows_offset(n_tiles > 0 ? n_tiles : 1) + nb * 16 * sizeof(float);
+  return gsl_vm_rows_offset(n_tiles > 0 ? n_tiles : 1) + (nb + GSL_VM_STAGE_ROWS) * 16 * sizeof(float);
 }
 
 // where gsl_fused_project_bwd leaves the pose-gradient rows inside ws: ceil(N / 256) rows of 16 floats (15 used)
@@ -1088,7 +1118,13 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
 #undef CALL_PB
   GSL_CHECK_LAUNCH();
   if (reduce_viewmat) {
-    hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
+    if (grid > 8192) {  // two stages (fixed order either way)
+      float* stage = partials + (size_t)grid * 16;
+      hipLaunchKernelGGL(gsl::k_freduce_rows, dim3(GSL_VM_STAGE_ROWS), dim3(256), 0, st, partials, grid, stage);
+      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, stage, GSL_VM_STAGE_ROWS, viewmat, K, v_viewmat);
+    } else {
+      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
+    }
     GSL_CHECK_LAUNCH();
   }
   return GSL_OK;

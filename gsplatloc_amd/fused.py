@@ -249,6 +249,9 @@ def cached_rasterization(means, quats, scales, opacities, colors, viewmat, K, wi
     rc = _cached_context(key, lambda: RenderContext(
         N, width, height, render_mode, sh_degree=sh_degree, K_sh=K_sh, device=means.device, eps2d=eps2d,
         near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, antialiased=antialiased, full_grads=False))
+    tensors = (means, quats, scales, opacities, colors, viewmat)
+    # hit lists only when somebody can back-propagate through this call (geometry.py:117-132 renders under no_grad)
+    rc.record_hits = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
     rc.allow_tiny = False  # a splat that outgrew the tiny backward is only known after the backward: not in this API
     rc.full_grads = True  # gradient buffers are allocated per call (owned by the caller), not by the context
     if rc.tiles_per_gauss is None:
