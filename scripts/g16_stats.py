@@ -31,9 +31,9 @@ lib.gsl_g16_stats(out, 1)
 ctx.backward(v, va, full=True)
 torch.cuda.synchronize()
 lib.gsl_g16_stats(out, 1)
-trips, valid, act, pairs, clash, lanes, wgmax, walked = [int(x) for x in out[:8]]
-print(f"walked (block, entry) pairs {walked} ({walked / max(trips, 1):.2f} rows busy per wave trip); per-batch max over the 4 waves summed {wgmax} "
-      f"-> barrier-bound wave trips {4 * wgmax} ({4 * wgmax / max(trips, 1):.2f}x the trips walked)")
-print(f"intersections {n_is}; wave trips {trips}, with a composited pixel {valid} ({valid / max(trips, 1):.2%}); "
-      f"active rows per trip {act / max(trips, 1):.2f}; (block, entry) pairs with a composited pixel {pairs} "
-      f"({pairs / max(valid, 1):.2f} per valid trip); composited (pixel, entry) pairs {lanes} ({lanes / max(pairs, 1):.2f} per pair); clash trips {clash} ({clash / max(valid, 1):.2%})")
+trips, valid, act, pairs, clash, lanes, kmax_sum, walked = [int(x) for x in out[:8]]
+print(f"workload R sigma {sigma}: intersections {n_is}")
+print(f"wave trips {trips} (sum over batches of the longest row list: {kmax_sum}); trips with a composited pixel {valid} "
+      f"({valid / max(trips, 1):.1%}); rows busy per trip {act / max(trips, 1):.2f} of 4")
+print(f"(block, entry) pairs walked {walked}; pairs with a composited pixel {pairs}; composited (pixel, entry) pairs {lanes} "
+      f"({lanes / max(pairs, 1):.2f} of 16 lanes per pair)")
