@@ -683,7 +683,12 @@ def main():
                                ((1.0, "raster"), (0.0, "random"), (0.0, "raster"))]
             out["variants"].append(guarded(variant_rate, dev, W * H, W, H, 0.0, "raster", depth_frame=True))
         th1 = throttle_stats()
-        out["host"] = {"cpu_share": host_cpu_share(), "host_cores": os.cpu_count(),
+        try:  # BENCH_r02 recorded one process still alive when the command returned: name whatever this process started
+            import psutil
+            kids = [f"{c.pid}:{c.name()}" for c in psutil.Process().children(recursive=True)]
+        except Exception:  # noqa: BLE001
+            kids = None
+        out["host"] = {"cpu_share": host_cpu_share(), "host_cores": os.cpu_count(), "child_processes_at_end": kids,
                        "cgroup_throttled": None if (throttle0 is None or th1 is None) else
                        {"periods": th1[0] - throttle0[0], "ms": th1[1] - throttle0[1]}}
         print(json.dumps(out))

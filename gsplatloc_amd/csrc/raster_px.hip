@@ -627,6 +627,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   if (capacity > 0 && !Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (isect_hits && !isect_hit_counts) return GSL_ERR_BAD_ARG;
+  if (isect_hits && capacity >= ((int64_t)1 << 28)) return GSL_ERR_BAD_ARG;  // a hit entry keeps the list index in 28 bits
   if (ty0 == ty1) return GSL_OK;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
