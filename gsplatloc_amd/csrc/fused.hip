@@ -131,7 +131,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
         }
         c0 = fmaxf(c0 + 0.5f, 0.f); c1 = fmaxf(c1 + 0.5f, 0.f); c2 = fmaxf(c2 + 0.5f, 0.f);
       }
-      GSL_Q(Q2, i) = make_float4(c0, c1, c2, 0.f);
+      if (!Qh) GSL_Q(Q2, i) = make_float4(c0, c1, c2, 0.f);  // (fp16 staging: the compositing kernels read the colour from Qh)
     }
     if (Qh) store_half_record(Qh, (size_t)i, o0, o1, make_float4(c0, c1, c2, 0.f));
     if (radius > 0) {

@@ -170,7 +170,7 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  * fp16 staging (Qh, may be NULL everywhere): gsl_fused_project additionally packs one 32-byte record per Gaussian
  *                     into Qh[N][8 dwords] -- centre float32, conic / cull radius / depth / opacity / colour as
  *                     halves -- and the compositing calls given Qh gather that record instead of Q0/Q1/Q2 (which may
- *                     then be NULL there).  Transmittance and every accumulator stay float32 (BASELINE.json
+ *                     then be NULL there; gsl_fused_project given Qh does not write Q2 at all).  Transmittance and every accumulator stay float32 (BASELINE.json
  *                     configs[4] "fp16 compositing").  Binning and gsl_fused_project_bwd keep reading
  *                     the float32 records, so the list order is the float32 order.
  * Deterministic mode (vrow, may be NULL): by default the backward accumulates with float atomics (LDS across the
