@@ -13,6 +13,7 @@ Mirrors what /root/reference/src/my_gsplat/gs_trainer_total.py:97-152 does per i
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Dict, Optional, Tuple
 
@@ -151,17 +152,18 @@ class RenderContext:
         near = sizes[sizes > long_min // 2]
         if not near.numel() or int(near.max()) <= int(long_min * 0.75):
             return
-        segs = int(torch.ceil(near.double() * max(headroom, 1.5) / 512.0).sum()) + 8
+        # every near-long tile's segments with head-room, plus three more copies of the longest list: a pile that sits
+        # on a tile corner appears in four tile lists at once, and it moves by tens of pixels per iteration
+        hr = max(headroom, 1.5)
+        segs = int(torch.ceil(near.double() * hr / 512.0).sum()) + 3 * int(math.ceil(float(near.max()) * hr / 512.0)) + 8
         self.long_min, self.max_seg = long_min, segs
         # merge passes of the long-list sort: runs of 512 keys doubled until they cover 1.5 x the longest list
-        import math
         self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * float(near.max()) / 512.0))))
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
     def grow_long(self, needed: int) -> None:
         """Recovery after long_overflowed(): a workspace for 1.5 x the segments the frame needed."""
-        import math
         self.long_min, self.max_seg = max(self.long_min, LONG_MIN), max(self.max_seg, int(needed * 1.5) + 8)
         self.long_passes = max(self.long_passes, math.ceil(math.log2(max(2.0, 1.5 * needed))))
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(self.max_seg)

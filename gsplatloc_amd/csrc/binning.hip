@@ -604,6 +604,7 @@ __global__ __launch_bounds__(64) void k_long_sort_seg(const int32_t* __restrict_
   int g = blockIdx.x;
   if (g >= w.n_seg[0]) return;
   int tile = w.seg_tile[g], sgm = w.seg_idx[g];
+  if (tile < 0) return;  // a tile whose segments did not fit the workspace (flagged by k_long_map)
   long long s = tile_offsets[tile], e = tile_offsets[tile + 1];
   if (e > capacity) e = capacity;
   int n = (int)min((long long)bin_cap, e - s);
@@ -641,6 +642,7 @@ __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ t
   int g = blockIdx.x;
   if (g >= w.n_seg[0]) return;
   int tile = w.seg_tile[g], sgm = w.seg_idx[g];
+  if (tile < 0) return;  // a tile whose segments did not fit the workspace (flagged by k_long_map)
   long long s = tile_offsets[tile], e = tile_offsets[tile + 1];
   if (e > capacity) e = capacity;
   int n = (int)min((long long)bin_cap, e - s);

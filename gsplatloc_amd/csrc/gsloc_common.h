@@ -346,12 +346,16 @@ static __global__ __launch_bounds__(1024) void k_long_map(const int32_t* __restr
     int woff = 0;
     for (int k = 0; k < wv; ++k) woff += wsum[k];
     int first = carry_s + woff + x - nseg;
+    // A tile is mapped with ALL its segments or not at all: the combine and the backward index a tile's segments
+    // first .. first + nseg - 1, which must exist.  Slots of a tile that does not fit get tile -1 (every kernel that walks
+    // the map returns on it); n_seg[1] then tells the host how many segments the frame needed.
+    const bool fits = first + nseg <= max_seg;
     for (int sgm = 0; sgm < nseg; ++sgm) {
       int g = first + sgm;
       if (g < max_seg) {
-        w.seg_tile[g] = tile;
-        w.seg_idx[g] = sgm;
-        w.seg_cnt[g] = nseg;
+        w.seg_tile[g] = fits ? tile : -1;
+        w.seg_idx[g] = fits ? sgm : -1;
+        w.seg_cnt[g] = fits ? nseg : 0;
       }
     }
     __syncthreads();

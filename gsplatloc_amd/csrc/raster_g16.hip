@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
     if (gseg >= lw.n_seg[0]) return;
     tile = lw.seg_tile[gseg];
     sgm = lw.seg_idx[gseg];
+    if (tile < 0) return;  // (segments that did not fit the workspace: flagged by k_long_map)
   } else {
     tile = ty0 * tile_w + item;
   }

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void k_long_fwd(
   int g = blockIdx.x;
   if (g >= w.n_seg[0]) return;
   int tile = w.seg_tile[g], sgm = w.seg_idx[g];
+  if (tile < 0) return;  // a tile whose segments did not fit the workspace (flagged by k_long_map)
   int tid = threadIdx.x;
   TilePixel tp = tile_pixel(tile, tile_w, tid);
   int i = tp.i, j = tp.j;
@@ -391,6 +392,7 @@ __global__ __launch_bounds__(256) void k_long_combine(int W, int H, int tile_w, 
   int g = blockIdx.x;
   if (g >= w.n_seg[0] || w.seg_idx[g] != 0) return;
   int tile = w.seg_tile[g], nseg = w.seg_cnt[g];
+  if (tile < 0) return;
   int tid = threadIdx.x;
   TilePixel tp = tile_pixel(tile, tile_w, tid);
   int i = tp.i, j = tp.j;

@@ -329,3 +329,48 @@ def test_long_tile_list_is_split_over_workgroups_and_matches_the_oracle():
     errs = _context_vs_c_oracle(f"pile N={N} 640x480, longest tile list {longest}", cpu, sc["viewmat"].cpu(), W, H,
                                 [_depth_upstream(H, W, seed=k) for k in (9, 10, 11)], 5e-3)
     assert errs["v_viewmat"] < 8e-4
+
+
+def test_long_list_workspace_overflow_is_flagged_not_overrun():
+    """A frame that needs more (tile, segment) pairs than the long-list workspace holds (a pile that jumps onto a tile
+    corner appears in up to four lists at once): tiles whose segments do not fit are left out as a whole and the need is
+    reported -- nothing is indexed past the workspace (round 3: the first GraphTracker run on a pile frame faulted
+    exactly there) -- and after grow_long() the result is the one of a context that had room from the start."""
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=1, holes=True, device=dev, pile=True)
+    N = sc["means"].shape[0]
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
+    v = _depth_upstream(H, W, seed=9).float().to(dev).contiguous()
+    va = torch.zeros(H, W, 1, device=dev)
+    ref = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    ref.calibrate(*inp)
+    assert ref.long_min > 0
+    r_ref, _ = ref.forward(*inp)
+    g_ref = ref.backward(v, va, full=True)["viewmat"].clone()
+    r_ref = r_ref.clone()
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    ctx.calibrate(*inp)
+    need = int(ctx.long_ws[:16].view(torch.int32)[0].item()) if False else None  # (n_seg is written by the forward)
+    # shrink the workspace below the pile's 46 segments
+    ctx.max_seg = 20
+    ctx.long_ws_bytes = ctx.lib.gsl_long_ws_bytes(ctx.max_seg)
+    ctx.long_ws = torch.zeros(ctx.long_ws_bytes, dtype=torch.uint8, device=dev)
+    guard = torch.full((1 << 20,), 0x5A, dtype=torch.uint8, device=dev)  # (allocated right after: a canary, not a proof)
+    ctx.forward(*inp)
+    ctx.backward(v, va, full=True)
+    torch.cuda.synchronize()
+    assert bool((guard == 0x5A).all())
+    need = ctx.long_overflowed()
+    assert need >= 46, need
+    with pytest.raises(RuntimeError, match="long tile lists need"):
+        ctx.check_capacity()
+    ctx.grow_long(need)
+    r, _ = ctx.forward(*inp)
+    g = ctx.backward(v, va, full=True)["viewmat"]
+    torch.cuda.synchronize()
+    assert ctx.long_overflowed() == 0
+    assert torch.equal(r, r_ref) and rel_inf(g[:3], g_ref[:3]) < 1e-5
