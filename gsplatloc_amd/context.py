@@ -110,6 +110,7 @@ class RenderContext:
         self.trec = self.vcT = None
         # long tile lists (a pile of splats in one tile): split over workgroups when calibrate() finds one
         self.long_min, self.max_seg, self.long_ws, self.long_ws_bytes, self.long_passes = 0, 0, None, 0, 0
+        self._mean_list = 0.0
         self.keys = self.flatten_ids = self.hits = None
         if capacity is not None:
             self._alloc_isects(int(capacity))
@@ -148,7 +149,8 @@ class RenderContext:
         # has ordinary lists of ~1 500 entries, and launching the long-list kernels over empty segment grids would cost it
         # 4 % for nothing
         nonempty = sizes[sizes > 0]
-        long_min = max(LONG_MIN, int(4.0 * float(nonempty.double().mean()))) if nonempty.numel() else LONG_MIN
+        self._mean_list = float(nonempty.double().mean()) if nonempty.numel() else 0.0
+        long_min = max(LONG_MIN, int(4.0 * self._mean_list))
         near = sizes[sizes > long_min // 2]
         if not near.numel() or int(near.max()) <= int(long_min * 0.75):
             return
@@ -203,7 +205,19 @@ class RenderContext:
         return int(f[2]) if f[1] else 0
 
     def grow_bins(self, longest: int) -> None:
+        """Recovery after bins_overflowed(): bins for 1.5 x the longest list seen -- and, if that list is long by the
+        frame's standards (a pile of invalid-depth points that came into view DURING the optimisation: it sits at the
+        previous camera's origin and passes the near plane only once the camera has moved back far enough), the
+        long-list split, which calibrate() could not have switched on."""
         self._alloc_bins(int(longest * 1.5) + 64)
+        if self.long_min == 0 and not self.deterministic and os.environ.get("GSLOC_LONG_LISTS", "1") != "0":
+            long_min = max(LONG_MIN, int(4.0 * self._mean_list))
+            if longest > int(long_min * 0.75):
+                segs = 4 * int(math.ceil(longest * 1.5 / 512.0)) + 8
+                self.long_min, self.max_seg = long_min, segs
+                self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * longest / 512.0))))
+                self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
+                self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
     def _choose_backward(self) -> None:
         """Tiny-splat backward (per-splat 4x4 record slabs, no reduction, no atomics) when no splat reaches

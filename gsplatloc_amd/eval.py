@@ -31,6 +31,7 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
     cfg = TrackerConfig(max_steps=num_iters)
     tracker = None
     eTs, eRs, steps = [], [], []
+    long_frames = 0  # frames with a tile list long enough to be split over workgroups (a pile of invalid-depth points)
     t0 = time.perf_counter()
     n = len(parser) if max_frames is None else min(len(parser), max_frames)
     for i in range(n):
@@ -41,6 +42,7 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
         tracker.load_frame(d.tar_points, d.colors, init_gs_scales(d.tar_points), d.src_depth, d.tar_c2w, d.src_c2w,
                            parser.K)
         res = tracker.run()
+        long_frames += int(tracker.rc.long_min > 0)
         # early stop never fired before min_step: fall back to the last iterate's errors, as the reference would log inf
         eTs.append(res.best_eT)
         eRs.append(res.best_eR)
@@ -55,7 +57,7 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
                 "error": "no frame produced a minimum-loss read-out (num_iters must exceed 101)"}
     return {"ATE": rmse([a for a, _ in finite]), "AAE": rmse([b for _, b in finite]), "frames": n,
             "frames_with_result": len(finite), "mean_steps": sum(steps) / max(len(steps), 1),
-            "seconds": dt, "frames_per_s": n / dt if dt > 0 else None}
+            "frames_with_long_lists": long_frames, "seconds": dt, "frames_per_s": n / dt if dt > 0 else None}
 
 
 def main(argv=None):

@@ -349,3 +349,30 @@ def test_graph_tracker_on_a_frame_with_a_pile():
     assert la[-1] < 0.5 * la[0]
     print(f"[perf] pile frame, tracker iteration: {ta * 1e3:.3f} ms split over workgroups, {tb * 1e3:.3f} ms one workgroup")
     assert ta < 0.5 * tb
+
+
+def test_pile_that_comes_into_view_during_the_optimisation_switches_the_split_on():
+    """The usual way a pile arises in GsplatLoc: the invalid points sit at the TARGET frame's camera origin, which is
+    where the optimisation starts (/root/reference/src/data/dataset.py:349-350: both clouds are placed with the target
+    pose), so at calibration they are behind the near plane; they only enter the view once the camera has moved back
+    far enough.  The bins sized at calibration then overflow, the poll sees it, and the recovery sizes the bins for the
+    pile AND switches the long-list split on (calibrate() could not have)."""
+    import gsplatloc_amd.my_gsplat as M
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=1, holes=True, device=DEV, pile=True)
+    N = sc["means"].shape[0]
+    gt_c2w = torch.linalg.inv(sc["viewmat"])          # 1.5 cm behind the previous camera: the pile is in view there
+    start = torch.eye(4, device=DEV)                  # the previous camera itself: the pile sits at z = 0, culled
+    rgb = (sc["sh"][:, 0, :] * 0.28209479177387814 + 0.5).contiguous()
+    target = M.compute_depth_gt(sc["means"], rgb, sc["K"][None], gt_c2w[None], H, W)
+    cfg = M.TrackerConfig(max_steps=150, min_step=5, patience=1000)
+    gt = GraphTracker(N, W, H, cfg, device=DEV, poll=25)
+    gt.load_frame(sc["means"], rgb, sc["scales"], target, start, gt_c2w, sc["K"])
+    assert gt.rc.long_min == 0 and int((gt.rc.offs[1:] - gt.rc.offs[:-1]).max()) < 2000
+    res = gt.run()
+    assert res.steps == 150 and torch.isfinite(torch.tensor(res.losses)).all()
+    assert gt.rc.long_min > 0 and gt.rc.bin_cap > 20_000, (gt.rc.long_min, gt.rc.bin_cap)
+    assert res.losses[-1] < 0.5 * res.losses[0]
