@@ -374,3 +374,44 @@ def test_long_list_workspace_overflow_is_flagged_not_overrun():
     torch.cuda.synchronize()
     assert ctx.long_overflowed() == 0
     assert torch.equal(r, r_ref) and rel_inf(g[:3], g_ref[:3]) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["ED", "RGB", "D"])
+def test_long_list_split_in_the_other_render_modes(mode):
+    """The pile frame in the one-channel and colour-only modes (other template instances of the long-list kernels and
+    of the per-quadrant backward): split over workgroups against the single-workgroup walk."""
+    import os
+
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=1, holes=True, device=dev, pile=True)
+    N = sc["means"].shape[0]
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
+    D = {"ED": 1, "D": 1, "RGB": 3}[mode]
+    g = torch.Generator().manual_seed(4)
+    v = torch.randn(H, W, D, generator=g).to(dev)
+    va = torch.randn(H, W, 1, generator=g).to(dev)
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["GSLOC_LONG_LISTS"] = flag
+        try:
+            ctx = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=dev, full_grads=True)
+            ctx.calibrate(*inp)
+        finally:
+            os.environ.pop("GSLOC_LONG_LISTS", None)
+        assert (ctx.long_min > 0) == (flag == "1")
+        # the general backward in both (the tiny-splat backward does not take colour-only upstream differently, but the
+        # point here is the long-list variant of the per-quadrant kernel)
+        ctx.use_general_backward()
+        render, alphas = ctx.forward(*inp)
+        gr = ctx.backward(v, va, full=True)
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        out[flag] = (render.clone(), alphas.clone(), gr["viewmat"].clone(), gr["means"].clone())
+    (r1, a1, gv1, gm1), (r0, a0, gv0, gm0) = out["1"], out["0"]
+    assert float((r1 - r0).abs().max()) < 2e-4 * max(1.0, float(r0.abs().max())) and float((a1 - a0).abs().max()) < 1e-5
+    assert rel_inf(gv1[:3], gv0[:3]) < 2e-4, rel_inf(gv1[:3], gv0[:3])
+    assert float((gm1 - gm0).norm() / gm0.norm()) < 2e-4
