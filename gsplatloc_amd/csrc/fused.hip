@@ -832,7 +832,15 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
       if (sh_degree < 0) {
         v_colors[3 * (size_t)i] = vrgb[0]; v_colors[3 * (size_t)i + 1] = vrgb[1]; v_colors[3 * (size_t)i + 2] = vrgb[2];
       } else {
-        for (int k = 0; k < K_sh * 3; ++k) v_colors[(size_t)i * K_sh * 3 + k] = 0.f;
+        // (12 coefficients = 48 bytes per Gaussian for SH degree 1: three 16-byte stores instead of twelve strided
+        // 4-byte ones; any other band count keeps the loop)
+        if (K_sh == 4) {
+          float4* dst = reinterpret_cast<float4*>(v_colors + (size_t)i * 12);
+          float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          dst[0] = z4; dst[1] = z4; dst[2] = z4;
+        } else {
+          for (int k = 0; k < K_sh * 3; ++k) v_colors[(size_t)i * K_sh * 3 + k] = 0.f;
+        }
       }
     }
   }
