@@ -76,7 +76,7 @@ class RenderContext:
         # size, [3] a binned projection started on uncleared tile counters
         self.status = torch.zeros(8, dtype=i32, device=dev)
         self.n_is = self.status[4:5]
-        self.hit_counts = torch.zeros(4 * self.n_tiles, dtype=i32, device=dev)  # lengths of the quadrants' hit lists
+        self.hit_counts = torch.zeros(4 * self.n_tiles + 1, dtype=i32, device=dev)  # lengths of the quadrants' hit lists
         self.ws_bytes = self.lib.gsl_fused_ws_bytes(N, self.n_tiles)
         self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.render = torch.zeros(self.H, self.W, self.D, dtype=f32, device=dev)

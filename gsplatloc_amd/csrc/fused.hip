@@ -1012,7 +1012,7 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
                                          const uint32_t* isect_hits, const int32_t* isect_hit_counts, int long_min,
-                                         void* long_ws, int max_seg, void* stream);
+                                         void* long_ws, int max_seg, int rgb_flag_index, void* stream);
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
@@ -1055,7 +1055,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   // non-deterministic path: 16-lane groups, one workgroup per quadrant (raster_g16.hip)
   return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                    capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                   isect_hits, isect_hit_counts, long_min, nullptr, 0, stream);
+                                   isect_hits, isect_hit_counts, long_min, nullptr, 0, 4 * tile_w * tile_h, stream);
 }
 
 // Compositing backward of the long tile lists (the segments gsl_long_raster_fwd listed in long_ws): adds into vacc.
@@ -1075,7 +1075,7 @@ extern "C" int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float
   if (!flatten_ids || (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2)))) return GSL_ERR_BAD_ARG;
   return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                    capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                   isect_hits, nullptr, long_min, long_ws, max_seg, stream);
+                                   isect_hits, nullptr, long_min, long_ws, max_seg, 0, stream);
 }
 
 extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,

@@ -388,8 +388,14 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
-    const uint32_t* __restrict__ isect_hits, const int32_t* __restrict__ isect_hit_counts, int long_min, LongWs lw) {
+    const uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts, int long_min, LongWs lw,
+    int32_t* __restrict__ rgb_flag) {
   __shared__ QStage<D, CG> sb;
+  // rgb_flag (may be NULL; D = 4 only): raised by the depth-only kernel when it leaves a quadrant to the full-colour
+  // kernel, cleared by the compositing forward.  The full-colour launch returns on a clear flag after one load per
+  // workgroup instead of reading its 64 pixels' upstream gradient to find out that it has nothing to do (GsplatLoc's
+  // loss: always).  A stale raised flag (a second backward after the same forward) only costs that reading.
+  if (D == 4 && CG == D && rgb_flag && *rgb_flag == 0) return;
   const int quad = blockIdx.x & 3, item = blockIdx.x >> 2;
   int tile, sgm = 0, gseg = 0;
   if (LONG) {
@@ -430,7 +436,10 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
   if (D == 4) {
     bool rgb_grad = (vc[0] != 0.f) || (vc[1] != 0.f) || (vc[2] != 0.f);
     bool any_rgb = __ballot(rgb_grad) != 0ull;
-    if ((CG == 1) == any_rgb) return;  // the other kernel's quadrant
+    if ((CG == 1) == any_rgb) {  // the other kernel's quadrant
+      if (CG == 1 && rgb_flag && lane == 0) atomicOr(rgb_flag, 1);
+      return;
+    }
   }
   float Aimg = inside ? alphas[pid] : 0.f;
   float T_final = 1.f - Aimg;
@@ -498,25 +507,27 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
                                          const uint32_t* isect_hits, const int32_t* isect_hit_counts, int long_min,
-                                         void* long_ws, int max_seg, void* stream) {
+                                         void* long_ws, int max_seg, int rgb_flag_index, void* stream) {
   // long_ws == NULL: the tiles of the strip (those longer than long_min, if > 0, are skipped);
   // long_ws != NULL: only the (tile, segment) pairs the forward's long-list pass listed there
   hipStream_t st = (hipStream_t)stream;
   int nblk = long_ws ? max_seg : (ty1 - ty0) * tile_w;
   gsl::LongWs lw = gsl::long_ws_views(long_ws ? long_ws : (void*)0, long_ws ? max_seg : 0);
   const bool lng = long_ws != nullptr;
+  // (the flag sits behind the 4 n_tiles hit-list lengths; the long-list launches, which have no lengths array, go without)
+  int32_t* rgb_flag = isect_hit_counts ? const_cast<int32_t*>(isect_hit_counts) + rgb_flag_index : nullptr;
 #define CALL_Q(DD, EE, CC)                                                                                   \
   do {                                                                                                       \
     if (lng)                                                                                                 \
       hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, true>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, isect_hit_counts, long_min, lw);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag);                            \
     else                                                                                                     \
       hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, false>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, isect_hit_counts, long_min, lw);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag);                            \
   } while (0)
   if (channels == 1) { if (ed) CALL_Q(1, true, 1); else CALL_Q(1, false, 1); }
   else if (channels == 3) { CALL_Q(3, false, 3); }

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
     int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
     int32_t* __restrict__ clear_state, uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts,
-    int long_min) {
+    int long_min, int n_tiles_total) {
   __shared__ PStage<D> sb;
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     clear_counts[tile] = 0;
     if (blockIdx.x == 0 && clear_state) *clear_state = 0;  // counters consumed and cleared: the next projection may bin
   }
+  // "some quadrant needs the full-colour backward" flag behind the hit-list lengths (raster_g16.hip): cleared here
+  if (isect_hit_counts && blockIdx.x == 0 && threadIdx.x == 0) isect_hit_counts[4 * n_tiles_total] = 0;
   int tid = threadIdx.x;
   TilePixel tp = tile_pixel(tile, tile_w, tid);
   int i = tp.i, j = tp.j;
@@ -638,7 +640,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
                      (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits,          \
-                     isect_hit_counts, long_min)
+                     isect_hit_counts, long_min, tile_w * tile_h)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
   GSL_CHECK_LAUNCH();

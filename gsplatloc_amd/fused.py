@@ -77,7 +77,7 @@ class _FusedRasterization(torch.autograd.Function):
             torch.empty(H, W, 1, dtype=f32, device=dev)
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
         hits = torch.empty(4 * cap, dtype=torch.int32, device=dev)  # per tile and quadrant: the entries it composited
-        hit_counts = torch.empty(4 * n_tiles, dtype=i32, device=dev)
+        hit_counts = torch.empty(4 * n_tiles + 1, dtype=i32, device=dev)
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
                                        ptr(last_ids), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, st),

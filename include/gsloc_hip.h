@@ -157,11 +157,12 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     backward: each 16-lane DPP row of a wave walks the list of its own 4x4 pixel block
  *                     (csrc/raster_g16.hip; deterministic mode: quadrant walk with per-splat pixel sums on the
  *                     matrix cores, v_mfma_f32_16x16x4_f32, exact f32, csrc/fused.hip).  isect_hits (uint32[4 x capacity])
- *                     + isect_hit_counts (int32[4 x n_tiles]), may be NULL together in both calls: the forward leaves, per
+ *                     + isect_hit_counts (int32[4 x n_tiles + 1]), may be NULL together in both calls: the forward leaves, per
  *                     tile and 8x8 quadrant, the list of the entries at least one of the quadrant's pixels composited --
  *                     (nibble of its four 4x4 blocks that did) << 28 | list index, in list order, at
  *                     isect_hits[4 start + quadrant x length ...] for the tile's list [start, start + length), its
- *                     length in isect_hit_counts[4 tile + quadrant] -- and the backward given the same arrays walks
+ *                     length in isect_hit_counts[4 tile + quadrant] (the extra last int is a flag between the
+ *                     backward's two launches) -- and the backward given the same arrays walks
  *                     exactly those (block, entry) pairs instead of scanning the tile's list and testing every splat's
  *                     alpha >= 1/255 disc against the blocks.  (Segments of long lists: same layout per segment, the
  *                     lengths live in long_ws.)  Only pixel rows [row0,row1)
