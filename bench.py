@@ -157,7 +157,7 @@ def implementation_bin_bytes(N, I, n_tiles):
 STAGE_KERNELS = {  # stage timer -> kernels it brackets (names as rocprofv3 prints them, template arguments dropped)
     "project_fwd": ("k_fproject<true, true>", "k_fproject<false, true>"), "bin": ("k_tile_sort",),
     "raster_fwd": ("k_praster_fwd", "k_long_fwd", "k_long_combine", "k_long_map"),
-    "raster_bwd": ("k_graster_bwd", "k_mraster_bwd", "k_tiny_bwd"),
+    "raster_bwd": ("k_qraster_bwd", "k_mraster_bwd", "k_tiny_bwd"),
     "project_bwd": ("k_fproject_bwd", "k_freduce_viewmat"),
 }
 
