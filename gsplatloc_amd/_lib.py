@@ -46,8 +46,10 @@ _SIGNATURES = {
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                      P, P, P, P, P, P, c_int, c_int, P, P, P, P, c_int, P]),
     "gsl_long_ws_bytes": (c_size_t, [c_int]),
+    "gsl_long_segment": (c_int, []),
+    "gsl_long_sort_segment": (c_int, []),
     "gsl_long_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                    P, P, P, c_int, c_int, P, P, c_int, P, c_size_t, c_int, P]),
+                                    P, P, P, c_int, c_int, P, P, c_int, P, c_size_t, c_int, c_int, P]),
     "gsl_long_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                     P, P, P, P, P, P, c_int, c_int, P, P, c_int, P, c_int, P]),
     "gsl_loss_ws_bytes": (c_size_t, [c_int, c_int]),

@@ -24,7 +24,7 @@ from ._lib import check, current_stream, load_library, ptr
 from .fused import _MODES, MAX_STRIP_TILES, alloc_records, tile_n_bits
 
 
-LONG_MIN = 2048   # a tile list longer than this is split over workgroups (segments of 512 entries)
+LONG_MIN = 2048   # a tile list longer than this is split over workgroups (segments of gsl_long_segment() entries)
 BIN_BYTES_MAX = 2 << 30  # per-tile key bins larger than this in total: stay with two-pass binning
 TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at most 4 pixel centres per axis
 
@@ -157,17 +157,19 @@ class RenderContext:
         # every near-long tile's segments with head-room, plus three more copies of the longest list: a pile that sits
         # on a tile corner appears in four tile lists at once, and it moves by tens of pixels per iteration
         hr = max(headroom, 1.5)
-        segs = int(torch.ceil(near.double() * hr / 512.0).sum()) + 3 * int(math.ceil(float(near.max()) * hr / 512.0)) + 8
+        seg = float(self.lib.gsl_long_segment())
+        segs = int(torch.ceil(near.double() * hr / seg).sum()) + 3 * int(math.ceil(float(near.max()) * hr / seg)) + 8
         self.long_min, self.max_seg = long_min, segs
-        # merge passes of the long-list sort: runs of 512 keys doubled until they cover 1.5 x the longest list
-        self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * float(near.max()) / 512.0))))
+        # merge passes of the long-list sort: runs of one sort segment doubled until they cover 1.5 x the longest list
+        self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * float(near.max()) / self.lib.gsl_long_sort_segment()))))
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
     def grow_long(self, needed: int) -> None:
         """Recovery after long_overflowed(): a workspace for 1.5 x the segments the frame needed."""
         self.long_min, self.max_seg = max(self.long_min, LONG_MIN), max(self.max_seg, int(needed * 1.5) + 8)
-        self.long_passes = max(self.long_passes, math.ceil(math.log2(max(2.0, 1.5 * needed))))
+        runs = needed * self.lib.gsl_long_segment() / self.lib.gsl_long_sort_segment()
+        self.long_passes = max(self.long_passes, math.ceil(math.log2(max(2.0, 1.5 * runs))))
         self.long_ws_bytes = self.lib.gsl_long_ws_bytes(self.max_seg)
         self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
@@ -176,7 +178,7 @@ class RenderContext:
         if self.long_ws is None:
             return 0
         st = self.long_ws[:16].view(torch.int32).tolist()
-        return int(st[1]) if st[1] else (int(st[2]) // 512 + 1 if st[2] else 0)
+        return int(st[1]) if st[1] else (int(st[2]) // self.lib.gsl_long_segment() + 1 if st[2] else 0)
 
     def _alloc_bins(self, bin_cap: int) -> None:
         """Fixed-capacity per-tile key bins: the projection kernel then bins directly (no scatter pass, no counter
@@ -213,9 +215,10 @@ class RenderContext:
         if self.long_min == 0 and not self.deterministic and os.environ.get("GSLOC_LONG_LISTS", "1") != "0":
             long_min = max(LONG_MIN, int(4.0 * self._mean_list))
             if longest > int(long_min * 0.75):
-                segs = 4 * int(math.ceil(longest * 1.5 / 512.0)) + 8
+                seg = float(self.lib.gsl_long_segment())
+                segs = 4 * int(math.ceil(longest * 1.5 / seg)) + 8
                 self.long_min, self.max_seg = long_min, segs
-                self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * longest / 512.0))))
+                self.long_passes = max(1, math.ceil(math.log2(max(2.0, 1.5 * longest / self.lib.gsl_long_sort_segment()))))
                 self.long_ws_bytes = self.lib.gsl_long_ws_bytes(segs)
                 self.long_ws = torch.zeros(self.long_ws_bytes, dtype=torch.uint8, device=self.device)
 
@@ -310,7 +313,7 @@ class RenderContext:
                                                ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
                                                ptr(self.hits) if self.record_hits else None,
                                                self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
-                                               current_stream()), "gsl_long_raster_fwd")
+                                               int(self.bins is not None), current_stream()), "gsl_long_raster_fwd")
 
     def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,

@@ -592,10 +592,10 @@ __global__ __launch_bounds__(256) void k_isect_offsets(const int64_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // Sort of a LONG tile list by several workgroups (binned mode).  One workgroup sorted such a list block-wise in 1.6 ms
 // (23 k keys: the pile of invalid TUM points) -- after the compositing of that list had been split
-// over workgroups it was three quarters of the iteration.  Now: every 512-key segment of the list is sorted in
+// over workgroups it was three quarters of the iteration.  Now: every GSL_SORT_SEG-key segment of the list is sorted in
 // registers by one wave (k_long_sort_seg, into the packed key array), then `passes` merge passes double the run length,
-// one wave per 512 outputs (merge path: the two diagonals of the chunk are located by binary search in the two runs,
-// the <= 512 inputs staged in LDS, every lane merges its 8 outputs), ping-ponging between the packed key array and the
+// one wave per GSL_SORT_SEG outputs (merge path: the two diagonals of the chunk are located by binary search in the two runs,
+// the <= GSL_SORT_SEG inputs staged in LDS, every lane merges its share of the outputs), ping-ponging between the packed key array and the
 // tile's bin; the last pass writes flatten_ids.  Same result as any stable sort of the (depth bits, id) keys.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_long_sort_seg(const int32_t* __restrict__ tile_offsets, long long capacity,
@@ -605,20 +605,24 @@ __global__ __launch_bounds__(64) void k_long_sort_seg(const int32_t* __restrict_
   if (g >= w.n_seg[0]) return;
   int tile = w.seg_tile[g], sgm = w.seg_idx[g];
   if (tile < 0) return;  // a tile whose segments did not fit the workspace (flagged by k_long_map)
+  // (the map lists compositing segments; the first of every GSL_SORT_SEG / GSL_SEG works as a sort segment)
+  if (sgm & (GSL_SORT_SEG / GSL_SEG - 1)) return;
+  sgm >>= GSL_SORT_SEG_LOG2 - GSL_SEG_LOG2;
   long long s = tile_offsets[tile], e = tile_offsets[tile + 1];
   if (e > capacity) e = capacity;
   int n = (int)min((long long)bin_cap, e - s);
   int lane = threadIdx.x;
-  const uint64_t* src = bins + (size_t)tile * (size_t)bin_cap + (size_t)sgm * GSL_SEG;
-  int m = min(GSL_SEG, n - sgm * GSL_SEG);
-  uint64_t k[8];
+  const uint64_t* src = bins + (size_t)tile * (size_t)bin_cap + (size_t)sgm * GSL_SORT_SEG;
+  int m = min(GSL_SORT_SEG, n - sgm * GSL_SORT_SEG);
+  constexpr int KPL = GSL_SORT_SEG / 64;  // keys per lane
+  uint64_t k[KPL];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) k[r] = (lane * 8 + r < m) ? src[lane * 8 + r] : ~0ull;
-  wave_sort_regs<3>(k, lane);
-  uint64_t* dst = keys + s + (size_t)sgm * GSL_SEG;
+  for (int r = 0; r < KPL; ++r) k[r] = (lane * KPL + r < m) ? src[lane * KPL + r] : ~0ull;
+  wave_sort_regs<GSL_SORT_SEG_LOG2 - 6>(k, lane);
+  uint64_t* dst = keys + s + (size_t)sgm * GSL_SORT_SEG;
 #pragma unroll
-  for (int r = 0; r < 8; ++r)
-    if (lane * 8 + r < m) dst[lane * 8 + r] = k[r];
+  for (int r = 0; r < KPL; ++r)
+    if (lane * KPL + r < m) dst[lane * KPL + r] = k[r];
 }
 
 // smallest ia in [lo, hi] such that the first d merged elements take ia from A (keys are unique)
@@ -633,16 +637,37 @@ __device__ __forceinline__ int merge_diag(const uint64_t* __restrict__ A, int le
   return lo;
 }
 
-// pass p: runs of (GSL_SEG << p) keys -> runs of twice that.  src / dst: the packed key array and the bins, alternating.
+// merge_diag by the 64 lanes of a wave together (every lane calls it and gets the result): 64 probes per round instead
+// of one, so a diagonal of a 16 k-key run costs 3 dependent global loads instead of 14 (the searches were most of a
+// merge pass: 7 us each, eight passes per frame)
+__device__ __forceinline__ int merge_diag_wave(const uint64_t* __restrict__ A, int lenA, const uint64_t* __restrict__ B,
+                                               int lenB, int d, int lane) {
+  int lo = max(0, d - lenB), hi = min(d, lenA);
+  while (lo < hi) {  // (wave-uniform)
+    int step = (hi - lo + 63) >> 6;
+    int mid = lo + lane * step;
+    bool pred = mid < hi && A[mid] <= B[d - 1 - mid];  // true exactly for the probes below the answer: a prefix of lanes
+    int k = __popcll(__ballot(pred));
+    int nhi = (lo + k * step < hi) ? lo + k * step : hi;  // probe k (if there is one) answered "not below"
+    lo = k > 0 ? lo + (k - 1) * step + 1 : lo;
+    hi = nhi;
+  }
+  return lo;
+}
+
+// pass p: runs of (GSL_SORT_SEG << p) keys -> runs of twice that.  src / dst: the packed key array and the bins, alternating.
 __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ tile_offsets, long long capacity,
                                                    uint64_t* __restrict__ bins, int bin_cap, uint64_t* __restrict__ keys,
                                                    int pass, int last, int32_t* __restrict__ flatten_ids, LongWs w) {
-  __shared__ uint64_t sk[GSL_SEG];
+  __shared__ uint64_t sk[GSL_SORT_SEG];
   __shared__ int s_split[4];
   int g = blockIdx.x;
   if (g >= w.n_seg[0]) return;
   int tile = w.seg_tile[g], sgm = w.seg_idx[g];
   if (tile < 0) return;  // a tile whose segments did not fit the workspace (flagged by k_long_map)
+  // (the map lists compositing segments; the first of every GSL_SORT_SEG / GSL_SEG works as a sort segment)
+  if (sgm & (GSL_SORT_SEG / GSL_SEG - 1)) return;
+  sgm >>= GSL_SORT_SEG_LOG2 - GSL_SEG_LOG2;
   long long s = tile_offsets[tile], e = tile_offsets[tile + 1];
   if (e > capacity) e = capacity;
   int n = (int)min((long long)bin_cap, e - s);
@@ -651,26 +676,31 @@ __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ t
   uint64_t* bbase = bins + (size_t)tile * (size_t)bin_cap;
   const uint64_t* src = (pass & 1) ? bbase : kbase;
   uint64_t* dst = (pass & 1) ? kbase : bbase;
-  int L = GSL_SEG << pass;
-  int pair_start = (sgm * GSL_SEG) / (2 * L) * (2 * L);
-  int o = sgm * GSL_SEG - pair_start;
+  int L = GSL_SORT_SEG << pass;
+  int pair_start = (sgm * GSL_SORT_SEG) / (2 * L) * (2 * L);
+  int o = sgm * GSL_SORT_SEG - pair_start;
   int lenA = max(0, min(L, n - pair_start)), lenB = max(0, min(L, n - pair_start - L));
-  int out_len = min(GSL_SEG, lenA + lenB - o);
+  int out_len = min(GSL_SORT_SEG, lenA + lenB - o);
   const uint64_t* A = src + pair_start;
   const uint64_t* B = src + pair_start + L;
-  if (lane < 2) {
-    int d = lane == 0 ? o : o + out_len;
-    int ia = merge_diag(A, lenA, B, lenB, d);
-    s_split[2 * lane] = ia;
-    s_split[2 * lane + 1] = d - ia;
+  {
+    int ia_lo = merge_diag_wave(A, lenA, B, lenB, o, lane);
+    int ia_hi = merge_diag_wave(A, lenA, B, lenB, o + out_len, lane);
+    if (lane == 0) {
+      s_split[0] = ia_lo;
+      s_split[1] = o - ia_lo;
+      s_split[2] = ia_hi;
+      s_split[3] = o + out_len - ia_hi;
+    }
   }
   __syncthreads();
   int ia0 = s_split[0], ib0 = s_split[1], na = s_split[2] - ia0, nb = s_split[3] - ib0;
   for (int q = lane; q < na; q += 64) sk[q] = A[ia0 + q];
   for (int q = lane; q < nb; q += 64) sk[na + q] = B[ib0 + q];
   __syncthreads();
-  // every lane merges its 8 outputs from the staged pieces
-  int d0 = min(lane * 8, out_len), d1 = min(lane * 8 + 8, out_len);
+  // every lane merges its GSL_SORT_SEG / 64 outputs from the staged pieces
+  constexpr int KPL = GSL_SORT_SEG / 64;
+  int d0 = min(lane * KPL, out_len), d1 = min(lane * KPL + KPL, out_len);
   int ia = merge_diag(sk, na, sk + na, nb, d0), ib = d0 - ia;
   for (int d = d0; d < d1; ++d) {
     uint64_t v;
@@ -813,7 +843,7 @@ extern "C" int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h
   hipStream_t st = (hipStream_t)stream;
   gsl::LongWs w = gsl::long_ws_views(long_ws, max_seg);
   hipLaunchKernelGGL(gsl::k_long_map, dim3(1), dim3(1024), 0, st, tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w,
-                     (long long)capacity, long_min, max_seg, GSL_SEG << passes, w);
+                     (long long)capacity, long_min, max_seg, GSL_SORT_SEG << passes, w);
   hipLaunchKernelGGL(gsl::k_long_sort_seg, dim3(max_seg), dim3(64), 0, st, tile_offsets, (long long)capacity, bins,
                      bin_cap, sort_keys, w);
   for (int p = 0; p < passes; ++p)

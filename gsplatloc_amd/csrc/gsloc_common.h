@@ -288,7 +288,15 @@ __device__ __forceinline__ void tiny_fold_slab(const float4* __restrict__ Q0, co
 }
 
 // ---- long tile lists split over workgroups (raster_px.hip: forward; raster_g16.hip: backward) -----------------------------
-#define GSL_SEG 512
+// GSL_SEG: entries per compositing segment (the walk of a segment is serial per pixel, so its length is the latency of
+// a pile frame: 512 -> 256 -> 128 took the pile frame's compositing from 0.50 to 0.37 to ... ms); GSL_SORT_SEG: keys per
+// sorted run of the long-list sort (a multiple of GSL_SEG: 8 keys per lane in registers).
+#ifndef GSL_SEG_LOG2
+#define GSL_SEG_LOG2 7
+#endif
+#define GSL_SEG (1 << GSL_SEG_LOG2)
+#define GSL_SORT_SEG_LOG2 9
+#define GSL_SORT_SEG (1 << GSL_SORT_SEG_LOG2)
 
 struct LongWs {  // views into the caller's long_ws (sized by gsl_long_ws_bytes)
   int32_t* n_seg;     // [4]: segments of this frame, max_seg overflow flag, -, -
@@ -321,9 +329,13 @@ __host__ __device__ __forceinline__ LongWs long_ws_views(void* ws, int max_seg) 
 static __global__ __launch_bounds__(1024) void k_long_map(const int32_t* __restrict__ tile_offsets, int tile_begin, int n_strip_tiles,
                                                    long long capacity, int long_min, int max_seg, int max_list, LongWs w) {
   __shared__ int wsum[16];
-  __shared__ int carry_s;
+  __shared__ int carry_s, n_long_s;
+  __shared__ int lt_tile[32], lt_first[32], lt_nseg[32];
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry_s = 0;
+  if (tid == 0) {
+    carry_s = 0;
+    n_long_s = 0;
+  }
   __syncthreads();
   for (int base = 0; base < n_strip_tiles; base += 1024) {
     int q = base + tid;
@@ -350,16 +362,43 @@ static __global__ __launch_bounds__(1024) void k_long_map(const int32_t* __restr
     // first .. first + nseg - 1, which must exist.  Slots of a tile that does not fit get tile -1 (every kernel that walks
     // the map returns on it); n_seg[1] then tells the host how many segments the frame needed.
     const bool fits = first + nseg <= max_seg;
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-      int g = first + sgm;
-      if (g < max_seg) {
-        w.seg_tile[g] = fits ? tile : -1;
-        w.seg_idx[g] = fits ? sgm : -1;
-        w.seg_cnt[g] = fits ? nseg : 0;
+    // the long tiles of this round (a handful at most) are noted in LDS and their slots written by all threads together
+    // (one thread writing its tile's 180 slots alone was 7 us of a pile frame)
+    if (nseg > 0) {
+      int k = atomicAdd(&n_long_s, 1);
+      if (k < 32) {
+        lt_tile[k] = fits ? tile : -1;
+        lt_first[k] = first;
+        lt_nseg[k] = nseg;
+      } else {  // (more long tiles than notes: this thread writes its own)
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+          int g = first + sgm;
+          if (g < max_seg) {
+            w.seg_tile[g] = fits ? tile : -1;
+            w.seg_idx[g] = fits ? sgm : -1;
+            w.seg_cnt[g] = fits ? nseg : 0;
+          }
+        }
       }
     }
     __syncthreads();
-    if (tid == 1023) carry_s = carry_s + woff + x;
+    int nl = min(n_long_s, 32);
+    for (int k = 0; k < nl; ++k) {
+      int t = lt_tile[k], f = lt_first[k], c = lt_nseg[k];
+      for (int sgm = tid; sgm < c; sgm += 1024) {
+        int g = f + sgm;
+        if (g < max_seg) {
+          w.seg_tile[g] = t;
+          w.seg_idx[g] = t >= 0 ? sgm : -1;
+          w.seg_cnt[g] = t >= 0 ? c : 0;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      carry_s = carry_s + woff + x;
+      n_long_s = 0;
+    }
     __syncthreads();
   }
   if (tid == 0) {

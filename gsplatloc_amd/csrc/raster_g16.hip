@@ -457,13 +457,29 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
     int pslot = quad * 64 + lane;  // the forward's thread index of this pixel
     if (inside && (long long)bin_final >= seg_end) {
       T_init = fabsf(lw.Tend[(size_t)gseg * 256 + pslot]);
-      for (int s2 = sgm + 1; s2 < nseg; ++s2) {
-        size_t slot = (size_t)(gseg - sgm + s2) * 256 + pslot;
-        if (lw.Tend[slot] == 2.f) break;
-        float dot = 0.f;
+      // colour partials of the later segments up to the one the pixel stopped in, in segment order; eight segments'
+      // records are requested together (a fringe pixel of a pile composites through tens of segments)
+      const float4* C4 = reinterpret_cast<const float4*>(lw.C);
+      bool stop = false;
+      for (int s0 = sgm + 1; s0 < nseg && !stop; s0 += 8) {
+        float t8[8];
+        float4 c8[8];
 #pragma unroll
-        for (int k = 0; k < D; ++k) dot += vc[k] * lw.C[slot * 4 + k];
-        Bp_init += dot;
+        for (int u = 0; u < 8; ++u) {
+          size_t slot = (size_t)(gseg - sgm + min(s0 + u, nseg - 1)) * 256 + pslot;
+          t8[u] = lw.Tend[slot];
+          c8[u] = C4[slot];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (stop || s0 + u >= nseg) continue;
+          if (t8[u] == 2.f) { stop = true; continue; }
+          float cc[4] = {c8[u].x, c8[u].y, c8[u].z, c8[u].w};
+          float dot = 0.f;
+#pragma unroll
+          for (int k = 0; k < D; ++k) dot += vc[k] * cc[k];
+          Bp_init += dot;
+        }
       }
     }
   }

@@ -369,8 +369,21 @@ __global__ __launch_bounds__(256) void k_long_fwd(
                        cur, nullptr, nh);
     w.P[slot] = T;
   } else {
+    // T0 = P_0 ... P_{sgm-1}, multiplied in segment order; the loads are issued eight at a time (one after the other
+    // they were 25 us of this pass on a 90-segment list)
     float T = 1.f;
-    for (int s = 0; s < sgm; ++s) T *= w.P[(size_t)(g - sgm + s) * 256 + tid];
+    {
+      const float* Pp = w.P + (size_t)(g - sgm) * 256 + tid;
+      int s = 0;
+      for (; s + 8 <= sgm; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = Pp[(size_t)(s + u) * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) T *= v[u];
+      }
+      for (; s < sgm; ++s) T *= Pp[(size_t)s * 256];
+    }
     bool dead = !inside || T <= GSL_T_STOP;  // stopped in an earlier segment
     bool done = dead;
     int cur = -1;
@@ -387,35 +400,71 @@ __global__ __launch_bounds__(256) void k_long_fwd(
   }
 }
 
+// 1024 threads: pixel = tid & 255, and the tile's segments are dealt to the four 256-thread groups in contiguous
+// quarters, walked in segment order (eight segments' records requested together), then joined in quarter order through
+// LDS -- a pixel that never stops reads every segment, and one thread doing that alone was 55 us on a 90-segment list.
 template <int D, bool ED>
-__global__ __launch_bounds__(256) void k_long_combine(int W, int H, int tile_w, float* __restrict__ render,
-                                                      float* __restrict__ alphas, int32_t* __restrict__ last_ids, int row0,
-                                                      int row1, LongWs w) {
+__global__ __launch_bounds__(1024) void k_long_combine(int W, int H, int tile_w, float* __restrict__ render,
+                                                       float* __restrict__ alphas, int32_t* __restrict__ last_ids, int row0,
+                                                       int row1, LongWs w) {
+  __shared__ float4 s_pix[3][256];
+  __shared__ float s_T[3][256];
+  __shared__ int s_last[3][256];
+  __shared__ int s_state[3][256];  // bit 0: visited a segment, bit 1: stopped
   int g = blockIdx.x;
   if (g >= w.n_seg[0] || w.seg_idx[g] != 0) return;
   int tile = w.seg_tile[g], nseg = w.seg_cnt[g];
   if (tile < 0) return;
-  int tid = threadIdx.x;
+  int tid = threadIdx.x & 255, quarter = threadIdx.x >> 8;
   TilePixel tp = tile_pixel(tile, tile_w, tid);
   int i = tp.i, j = tp.j;
   bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
-  if (!inside) return;
-  float pix[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) pix[k] = 0.f;
+  float pix[4] = {0.f, 0.f, 0.f, 0.f};
   float T = 1.f;
-  int last = 0;
-  for (int s = 0; s < nseg; ++s) {
-    size_t slot = (size_t)(g + s) * 256 + tid;
-    float t = w.Tend[slot];
-    if (t == 2.f) break;  // dead on arrival: the pixel stopped at the very end of the previous segment
-    int l = w.last[slot];
+  int last = -1;
+  bool stop = false, visited = false;
+  const float4* C4 = reinterpret_cast<const float4*>(w.C);
+  int per = (nseg + 3) >> 2, sb = quarter * per, se = min(sb + per, nseg);
+  for (int s0 = sb; s0 < se && !stop && inside; s0 += 8) {
+    float t8[8];
+    int l8[8];
+    float4 c8[8];
 #pragma unroll
-    for (int k = 0; k < D; ++k) pix[k] += w.C[slot * 4 + k];
-    if (l >= 0) last = l;
-    T = fabsf(t);
-    if (t < 0.f) break;  // the pixel stopped inside segment s
+    for (int u = 0; u < 8; ++u) {
+      size_t slot = (size_t)(g + min(s0 + u, se - 1)) * 256 + tid;
+      t8[u] = w.Tend[slot];
+      l8[u] = w.last[slot];
+      c8[u] = C4[slot];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (stop || s0 + u >= se) continue;
+      float t = t8[u];
+      if (t == 2.f) { stop = true; continue; }  // dead on arrival: the pixel stopped at the very end of the previous segment
+      pix[0] += c8[u].x; pix[1] += c8[u].y; pix[2] += c8[u].z; pix[3] += c8[u].w;
+      if (l8[u] >= 0) last = l8[u];
+      T = fabsf(t);
+      visited = true;
+      if (t < 0.f) stop = true;  // the pixel stopped inside this segment
+    }
   }
+  if (quarter > 0) {
+    s_pix[quarter - 1][tid] = make_float4(pix[0], pix[1], pix[2], pix[3]);
+    s_T[quarter - 1][tid] = T;
+    s_last[quarter - 1][tid] = last;
+    s_state[quarter - 1][tid] = (visited ? 1 : 0) | (stop ? 2 : 0);
+  }
+  __syncthreads();
+  if (quarter != 0 || !inside) return;
+  for (int q = 0; q < 3 && !stop; ++q) {  // what the later quarters found counts only while no earlier one stopped
+    float4 c = s_pix[q][tid];
+    int st = s_state[q][tid];
+    pix[0] += c.x; pix[1] += c.y; pix[2] += c.z; pix[3] += c.w;
+    if (s_last[q][tid] >= 0) last = s_last[q][tid];
+    if (st & 1) T = s_T[q][tid];
+    stop = (st & 2) != 0;
+  }
+  if (last < 0) last = 0;
   size_t pid = (size_t)i * W + j;
   float A = 1.f - T;
   alphas[pid] = A;
@@ -648,6 +697,9 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
 }
 
 // ---- long tile lists (see the comment above k_long_map) ----------------------------------------------------------------
+extern "C" int gsl_long_segment(void) { return GSL_SEG; }
+extern "C" int gsl_long_sort_segment(void) { return GSL_SORT_SEG; }
+
 extern "C" size_t gsl_long_ws_bytes(int max_seg) {
   if (max_seg <= 0) return 0;
   size_t b = 16 + (size_t)(3 + 4) * max_seg * 4 + 256;
@@ -658,7 +710,8 @@ extern "C" int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float
                                    int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                    const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
                                    int32_t* last_ids, int row0, int row1, const void* Qh, uint32_t* isect_hits,
-                                   int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, void* stream) {
+                                   int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, int map_ready,
+                                   void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1 || long_min <= 0 || max_seg <= 0)
     return GSL_ERR_BAD_ARG;
@@ -669,9 +722,11 @@ extern "C" int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float
   if (ty0 == ty1 || capacity == 0) return GSL_OK;
   hipStream_t st = (hipStream_t)stream;
   gsl::LongWs w = gsl::long_ws_views(long_ws, max_seg);
-  hipLaunchKernelGGL(gsl::k_long_map, dim3(1), dim3(1024), 0, st, tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w,
-                     (long long)capacity, long_min, max_seg, 0, w);
-  GSL_CHECK_LAUNCH();
+  if (!map_ready) {  // (gsl_long_sort of the same frame, strip and long_min has listed the segments already)
+    hipLaunchKernelGGL(gsl::k_long_map, dim3(1), dim3(1024), 0, st, tile_offsets, ty0 * tile_w, (ty1 - ty0) * tile_w,
+                       (long long)capacity, long_min, max_seg, 0, w);
+    GSL_CHECK_LAUNCH();
+  }
 #define CALL_LF(DD, EE)                                                                                          \
   do {                                                                                                           \
     hipLaunchKernelGGL((gsl::k_long_fwd<DD, 0>), dim3(max_seg), dim3(256), 0, st, (const float4*)Q0,             \
@@ -680,7 +735,7 @@ extern "C" int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float
     hipLaunchKernelGGL((gsl::k_long_fwd<DD, 1>), dim3(max_seg), dim3(256), 0, st, (const float4*)Q0,             \
                        (const float4*)Q1, (const float4*)Q2, width, height, tile_w, tile_offsets, flatten_ids,   \
                        (long long)capacity, row0, row1, (const uint4*)Qh, isect_hits, w);                        \
-    hipLaunchKernelGGL((gsl::k_long_combine<DD, EE>), dim3(max_seg), dim3(256), 0, st, width, height, tile_w,    \
+    hipLaunchKernelGGL((gsl::k_long_combine<DD, EE>), dim3(max_seg), dim3(1024), 0, st, width, height, tile_w,   \
                        render, alphas, last_ids, row0, row1, w);                                                 \
   } while (0)
   GSL_P_DISPATCH(channels, ed, CALL_LF)

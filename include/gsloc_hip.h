@@ -234,7 +234,7 @@ int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int 
                          const int32_t* isect_hit_counts, int long_min, void* stream);
 /* Long tile lists split over workgroups (long_min > 0 in the calls above and in gsl_tiny_raster_bwd: tiles whose list
  * is longer than long_min entries are skipped there and handled here).  A pile of splats in one tile -- the invalid
- * pixels of a TUM depth frame, /root/reference/src/data/Image.py:29-35 -- is cut into segments of 512 entries, one
+ * pixels of a TUM depth frame, /root/reference/src/data/Image.py:29-35 -- is cut into segments of gsl_long_segment() entries, one
  * workgroup each: the forward computes per-pixel segment transmittances, restarts every segment from the product of
  * the earlier ones and combines the partial images; the backward restarts every segment from the stored state.
  * long_ws: gsl_long_ws_bytes(max_seg) bytes, zero-filled once; max_seg bounds the (tile, segment) pairs of a frame
@@ -242,8 +242,10 @@ int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int 
  * gsl_long_raster_fwd after gsl_fused_raster_fwd, gsl_long_raster_bwd after gsl_fused_raster_bwd / gsl_tiny_raster_bwd
  * (it adds into vacc; gsl_fused_project_bwd given both tiny_trec and vacc consumes both). */
 size_t gsl_long_ws_bytes(int max_seg);
+int gsl_long_segment(void);      /* entries per compositing segment (callers size max_seg with it) */
+int gsl_long_sort_segment(void); /* keys per sorted run of gsl_long_sort before its merge passes (sizes `passes`) */
 /* Binned mode only: gsl_fused_bin(long_min > 0) leaves the lists longer than long_min unsorted, and gsl_long_sort (call it
- * right after) sorts them with one wave per 512-key segment (registers) + `passes` merge-path passes (2^passes segments per
+ * right after) sorts them with one wave per gsl_long_sort_segment() keys (registers) + `passes` merge-path passes (2^passes such runs per
  * list at most; a longer list sets long_ws[2] (int32)), ping-ponging between sort_keys (scratch, packed) and the tile's
  * bin; flatten_ids receives the result.  One workgroup used to take 1.6 ms for a 23 k-entry list. */
 int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
@@ -253,7 +255,9 @@ int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int c
                         int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                         const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
                         int32_t* last_ids, int row0, int row1, const void* Qh, uint32_t* isect_hits,
-                        int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, void* stream);
+                        int long_min, void* long_ws, size_t long_ws_bytes, int max_seg, int map_ready, void* stream);
+/* map_ready != 0: gsl_long_sort has already listed this frame's (tile, segment) pairs for the same strip, long_min and
+ * max_seg in long_ws (binned mode); 0: list them here. */
 int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                         int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                         const int32_t* flatten_ids, int64_t capacity, const float* render,

@@ -5,7 +5,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gsplatloc_amd.context import RenderContext, time_stages  # noqa: E402
 from gsplatloc_amd.my_gsplat.geometry import depth_to_points, init_gs_scales  # noqa: E402
 from gsplatloc_amd.synthetic import SH_C0, frame_pair  # noqa: E402

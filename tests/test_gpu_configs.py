@@ -316,7 +316,7 @@ def test_long_tile_list_is_split_over_workgroups_and_matches_the_oracle():
         out[mode] = (render.clone(), alphas.clone(), ctx.last_ids.clone(), g["viewmat"].clone(), g["means"].clone(),
                      ctx.flatten_ids[:n].clone(), ctx.offs.clone())
     (r1, a1, l1, gv1, gm1, ids1, offs1), (r0, a0, l0, gv0, gm0, ids0, offs0) = out["1"], out["0"]
-    # the long list is sorted by several workgroups (512-key segments in registers + merge passes): bit for bit the
+    # the long list is sorted by several workgroups (one segment per wave in registers + merge passes): bit for bit the
     # order of the single-workgroup sort
     assert torch.equal(offs1, offs0) and torch.equal(ids1, ids0)
     # same per-pixel sequence of composited splats; only the association of the transmittance product differs
