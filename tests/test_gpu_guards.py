@@ -55,17 +55,20 @@ def _check(homes):
     (30_011, 640, 470, 1.0, (19, 30), "ED", False),       # strip at the bottom edge, partial last tile row
     (200_000, 1200, 680, 1.0, (22, 43), "RGB+ED", True),  # the rank-1-of-2 strip of the benchmark frame
 ])
-def test_no_write_outside_buffers(N, W, H, sigma_px, rows, mode, full):
+def test_no_write_outside_buffers(N, W, H, sigma_px, rows, mode, full, monkeypatch):
     from gsplatloc_amd.context import RenderContext
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
 
     dev = torch.device("cuda")
+    if sigma_px == 0.0:  # the tiny-splat backward, which "auto" keeps for Gaussians in pixel order (these are not)
+        monkeypatch.setenv("GSLOC_BWD", "tiny")
     sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev)
     viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
     K = sc["K"].contiguous()
     ctx = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full)
     inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
     ctx.calibrate(*inp, headroom=1.05)
+    assert ctx.tiny == (sigma_px == 0.0)
     homes = _rehome(ctx)
     g = torch.Generator().manual_seed(3)
     v = torch.randn(H, W, ctx.D, generator=g).to(dev)

@@ -387,21 +387,21 @@ def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
         v[..., :3] = 0  # the tracker's situation: only the depth channel carries a gradient
     va = torch.randn(H, W, 1, generator=gen).to(DEV)
     out = {}
-    for which in ("auto", "general"):
+    for which in ("tiny", "general"):  # ("auto" would pick the general backward: the scene's Gaussians are in random order)
         monkeypatch.setenv("GSLOC_BWD", which)
         rc = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=DEV, full_grads=full)
         rc.calibrate(*ins, V, K)
-        assert rc.tiny == (which == "auto")
+        assert rc.tiny == (which == "tiny")
         for _ in range(2):  # twice: the slabs / rows must come back clean
             rc.forward(*ins, V, K)
             g = rc.backward(v, va, full=full)
         rc.check_capacity()
         out[which] = {k: (t.clone() if t is not None else None) for k, t in g.items()}
-    assert rel_inf(out["auto"]["viewmat"], out["general"]["viewmat"]) < 2e-5
+    assert rel_inf(out["tiny"]["viewmat"], out["general"]["viewmat"]) < 2e-5
     if full:
         for k in ("means", "scales", "opacities", "colors"):
             scale = float(out["general"][k].abs().max())
-            mostly_close(out["auto"][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
+            mostly_close(out["tiny"][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
 
 
 def test_binned_projection_gives_the_lists_of_two_pass_binning():
@@ -619,12 +619,13 @@ def test_deterministic_backward_is_bit_reproducible(mode, full):
     assert rel_inf(runs[0]["viewmat"], runs[2]["viewmat"]) < 2e-5
 
 
-def test_tiny_backward_reports_a_splat_that_outgrew_its_slab():
+def test_tiny_backward_reports_a_splat_that_outgrew_its_slab(monkeypatch):
     """A context calibrated on pixel-sized splats whose scales then grow (sigma_px = 1: 8+ px wide): the tiny
     backward raises its sticky device flag instead of dropping gradient silently; the caller switches the context
     to the general backward and gets the right gradient."""
     _gpu()
     from gsplatloc_amd.context import RenderContext
+    monkeypatch.setenv("GSLOC_BWD", "tiny")  # (the scene's Gaussians are in random order: "auto" would not pick it)
     W, H, N = 96, 64, 3000
     small, big = _scene32(N, W, H, sigma_px=0.0), _scene32(N, W, H, sigma_px=1.0)
     sh = sh_from_rgb(small["rgbs"]).to(DEV)

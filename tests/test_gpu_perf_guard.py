@@ -54,7 +54,8 @@ def test_sigma0_step_at_R_size_stays_below_1ms(kind, order, bound_ms):
     ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
     inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], V, sc["K"].contiguous())
     ctx.calibrate(*inp)
-    assert ctx.tiny, "sub-pixel splats must select the tiny-splat backward"
+    # sub-pixel splats in pixel / tile order select the tiny-splat backward; in random order the general one is faster
+    assert ctx.tiny == (order == "raster")
     g = torch.Generator().manual_seed(1)
     v = torch.zeros(H, W, 4)
     v[..., 3] = torch.randn(H, W, generator=g)
