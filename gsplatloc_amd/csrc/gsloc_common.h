@@ -9,6 +9,7 @@
 #define GSL_ALPHA_MAX 0.999f
 #define GSL_ALPHA_MIN (1.0f / 255.0f)
 #define GSL_T_STOP 1e-4f
+#define GSL_LOG2E 1.4426950408889634f
 
 #define GSL_CHECK_LAUNCH()                                   \
   do {                                                       \

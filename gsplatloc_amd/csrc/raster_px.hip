@@ -150,8 +150,11 @@ __device__ __forceinline__ void praster_walk(
       float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
       load_record(Q0, Q1, Q2, Qh, g, RGB && MODE == 0, r0, r1, r2);
       sb.s0[tid] = r0;
-      sb.s1[tid] = r1;
-      if (RGB && MODE == 0) sb.s2[tid] = r2;
+      // staged for the walk: the conic times log2(e) (and its diagonal halved), so that a trip gets
+      // log2(e) sigma = a' dx^2 + c' dy^2 + b' dx dy in six operations and alpha = opacity exp2(-that) without the scaling
+      // multiply of expf; the depth rides in the colour record's spare lane (one packed accumulate for the four channels)
+      sb.s1[tid] = make_float4(r1.x * (0.5f * GSL_LOG2E), r1.y * GSL_LOG2E, r1.z * (0.5f * GSL_LOG2E), r1.w);
+      if (RGB && MODE == 0) sb.s2[tid] = make_float4(r2.x, r2.y, r2.z, r0.z);
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     for (int c = 0; c < n; c += 64) {
@@ -190,10 +193,10 @@ __device__ __forceinline__ void praster_walk(
           float4 p0 = sb.s0[t0], p1 = sb.s1[t0];
           float4 u0 = sb.s0[t1], u1 = sb.s1[t1];
           float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
-          float sg0 = 0.5f * (p1.x * dx0 * dx0 + p1.z * dy0 * dy0) + p1.y * dx0 * dy0;
-          float sg1 = 0.5f * (u1.x * dx1 * dx1 + u1.z * dy1 * dy1) + u1.y * dx1 * dy1;
-          float al0 = fminf(GSL_ALPHA_MAX, p0.w * __expf(-sg0));
-          float al1 = fminf(GSL_ALPHA_MAX, u0.w * __expf(-sg1));
+          float sg0 = fmaf(p1.y * dx0, dy0, fmaf(p1.x * dx0, dx0, p1.z * dy0 * dy0));  // log2(e) sigma (see the staging)
+          float sg1 = fmaf(u1.y * dx1, dy1, fmaf(u1.x * dx1, dx1, u1.z * dy1 * dy1));
+          float al0 = fminf(GSL_ALPHA_MAX, p0.w * __builtin_amdgcn_exp2f(-sg0));
+          float al1 = fminf(GSL_ALPHA_MAX, u0.w * __builtin_amdgcn_exp2f(-sg1));
           const bool ok0 = act && sg0 >= 0.f && al0 >= GSL_ALPHA_MIN;
           const bool ok1 = two && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN;
           if (MODE == 1) {
@@ -213,11 +216,15 @@ __device__ __forceinline__ void praster_walk(
           const float vis1 = stop1 ? 0.f : a1 * T1;
           T = stop1 ? T1 : nT1;
           if (RGB) {
-            float4 q20 = sb.s2[t0], q21 = sb.s2[t1];
+            float4 q20 = sb.s2[t0], q21 = sb.s2[t1];  // (r, g, b, depth)
             pix[0] += q20.x * vis0; pix[1] += q20.y * vis0; pix[2] += q20.z * vis0;
+            if (DEPTH) pix[D - 1] += q20.w * vis0;
             pix[0] += q21.x * vis1; pix[1] += q21.y * vis1; pix[2] += q21.z * vis1;
+            if (DEPTH) pix[D - 1] += q21.w * vis1;
+          } else if (DEPTH) {
+            pix[D - 1] += p0.z * vis0;
+            pix[D - 1] += u0.z * vis1;
           }
-          if (DEPTH) { pix[D - 1] += p0.z * vis0; pix[D - 1] += u0.z * vis1; }
           const bool c0 = vis0 > 0.f, c1 = vis1 > 0.f;  // composited (alpha >= 1/255 and T > 1e-4: the product is > 0)
           const int tsel = c1 ? t1 : t0;
           cur_idx = (c0 || c1) ? (int)bstart + tsel : cur_idx;
