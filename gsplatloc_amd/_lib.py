@@ -22,6 +22,7 @@ P = c_void_p  # every device pointer travels as void*
 _SIGNATURES = {
     "gsl_version": (c_char_p, []),
     "gsl_status_string": (c_char_p, [c_int]),
+    "gsl_dev_poison_lds": (c_int, [ctypes.c_uint32, P]),
     "gsl_project_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
                                 P, P, P, P, P, P]),
     "gsl_project_bwd_ws_bytes": (c_size_t, [c_int]),

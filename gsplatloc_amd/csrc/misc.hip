@@ -27,4 +27,22 @@ int zero_u32(void* p, size_t n_dwords, hipStream_t st) {
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
+
+// Diagnostics: fills the LDS of every CU with a bit pattern (gsl_dev_poison_lds).  The compositing kernels let a lane
+// without a candidate read SOME staged slot and multiply it by an exact zero, so every slot they can read must have been
+// written in the same batch: a test runs them after LDS has been filled with NaNs and expects bit-identical results.
+__global__ __launch_bounds__(1024) void k_poison_lds(uint32_t pattern, uint32_t* __restrict__ sink) {
+  extern __shared__ uint32_t lds[];
+  const int n = 65536 / 4;
+  for (int i = threadIdx.x; i < n; i += 1024) lds[i] = pattern;
+  __syncthreads();
+  if (sink && lds[(threadIdx.x * 7) % n] != pattern) sink[0] = 1;  // (keeps the stores alive)
+}
 }  // namespace gsl
+
+extern "C" int gsl_dev_poison_lds(uint32_t pattern, void* stream) {
+  // 64 KB per workgroup, 2048 workgroups: two per CU at a time, so every CU's LDS is written a few times over
+  hipLaunchKernelGGL(gsl::k_poison_lds, dim3(2048), dim3(1024), 65536, (hipStream_t)stream, pattern, (uint32_t*)nullptr);
+  GSL_CHECK_LAUNCH();
+  return GSL_OK;
+}

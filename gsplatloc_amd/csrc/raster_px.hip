@@ -155,6 +155,12 @@ __device__ __forceinline__ void praster_walk(
       // multiply of expf; the depth rides in the colour record's spare lane (one packed accumulate for the four channels)
       sb.s1[tid] = make_float4(r1.x * (0.5f * GSL_LOG2E), r1.y * GSL_LOG2E, r1.z * (0.5f * GSL_LOG2E), r1.w);
       if (RGB && MODE == 0) sb.s2[tid] = make_float4(r2.x, r2.y, r2.z, r0.z);
+    } else {
+      // every slot holds finite numbers: a lane without a candidate reads SOME slot in the straight-line trip and
+      // multiplies what it finds by an exact zero (stale LDS bits can be NaN)
+      sb.s0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sb.s1[tid] = make_float4(0.f, 0.f, 0.f, -1.f);
+      if (RGB && MODE == 0) sb.s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     for (int c = 0; c < n; c += 64) {
@@ -566,6 +572,11 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
       sb.s0[tid] = r0;
       sb.s1[tid] = r1;
       if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
+    } else {  // (finite numbers in every slot: see praster_walk)
+      sb.id[tid] = 0;
+      sb.s0[tid] = r0;
+      sb.s1[tid] = r1;
+      if (RGB) sb.s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     int t_first = (int)max((long long)0, bend - (long long)wave_final);
@@ -587,40 +598,62 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         unsigned m = half ? mhi : mlo;
+        // straight-line trips under a wave-uniform loop, two candidates per trip (as in praster_walk): a lane without a
+        // candidate, or whose candidate fails the alpha tests, runs the arithmetic with alpha 0 (1 / (1 - alpha) = 1:
+        // T and the running sum stay as they are) and stores nothing
         while (__ballot(m != 0)) {
-          if (m != 0) {
-            int bit = __ffs((int)m) - 1;
-            m &= m - 1;
-            int t = sb.qlist[wv][c + half * 32 + bit];
-            if (t >= t_lane) {
-              float4 q0 = sb.s0[t], q1 = sb.s1[t];
-              float dx = q0.x - px, dy = q0.y - py;
-              float gx = q1.x * dx + q1.y * dy;
-              float gy = q1.y * dx + q1.z * dy;
-              float sigma = 0.5f * (dx * gx + dy * gy);
-              float vis = __expf(-sigma);
-              float opv = q0.w * vis;
-              float alpha = fminf(GSL_ALPHA_MAX, opv);
-              if (sigma >= 0.f && alpha >= GSL_ALPHA_MIN) {
-                float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-                T *= ra;
-                float fac = alpha * T;
-                float cdot = 0.f;
-                if (RGB) {
-                  float4 q2 = sb.s2[t];
-                  cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
-                }
-                if (DEPTH) cdot += q0.z * vc[D - 1];
-                float v_alpha = T * cdot - ra * Bp;
-                Bp += fac * cdot;
-                float w = (opv <= GSL_ALPHA_MAX) ? vis * v_alpha : 0.f;
-                int cc = j - tiny_origin(q0.x, q1.w), rr = i - tiny_origin(q0.y, q1.w);
-                if ((unsigned)cc < 4u && (unsigned)rr < 4u)
-                  trec[(size_t)sb.id[t] * 16 + rr * 4 + cc] = make_float2(w, fac);
-                else if (flags)
-                  flags[0] = 1;  // sticky: the splat outgrew its 4x4 slab (r_cull >= 2 px); polled by the host
-              }
-            }
+          const bool act = m != 0;
+          const int bit0 = (__ffs((int)m) - 1) & 31;
+          m &= m - 1;
+          const bool two = m != 0;
+          const int bit1 = two ? __ffs((int)m) - 1 : bit0;
+          m &= m - 1;
+          const int t0 = sb.qlist[wv][c + half * 32 + bit0] & 255;
+          const int t1 = sb.qlist[wv][c + half * 32 + bit1] & 255;
+          float4 p0 = sb.s0[t0], p1 = sb.s1[t0];
+          float4 u0 = sb.s0[t1], u1 = sb.s1[t1];
+          float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
+          float sg0 = 0.5f * (dx0 * (p1.x * dx0 + p1.y * dy0) + dy0 * (p1.y * dx0 + p1.z * dy0));
+          float sg1 = 0.5f * (dx1 * (u1.x * dx1 + u1.y * dy1) + dy1 * (u1.y * dx1 + u1.z * dy1));
+          float vis0 = __expf(-sg0), vis1 = __expf(-sg1);
+          float opv0 = p0.w * vis0, opv1 = u0.w * vis1;
+          float al0 = fminf(GSL_ALPHA_MAX, opv0), al1 = fminf(GSL_ALPHA_MAX, opv1);
+          const bool ok0 = act && t0 >= t_lane && sg0 >= 0.f && al0 >= GSL_ALPHA_MIN;
+          const bool ok1 = two && t1 >= t_lane && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN;
+          float cd0 = 0.f, cd1 = 0.f;
+          if (RGB) {
+            float4 q20 = sb.s2[t0], q21 = sb.s2[t1];
+            cd0 = q20.x * vc[0] + q20.y * vc[1] + q20.z * vc[2];
+            cd1 = q21.x * vc[0] + q21.y * vc[1] + q21.z * vc[2];
+          }
+          if (DEPTH) { cd0 += p0.z * vc[D - 1]; cd1 += u0.z * vc[D - 1]; }
+          const float a0 = ok0 ? al0 : 0.f, a1 = ok1 ? al1 : 0.f;
+          const float ra0 = ok0 ? __builtin_amdgcn_rcpf(1.f - al0) : 1.f;
+          const float ra1 = ok1 ? __builtin_amdgcn_rcpf(1.f - al1) : 1.f;
+          const float T0 = T * ra0;
+          const float fac0 = a0 * T0;
+          const float va0 = T0 * cd0 - ra0 * Bp;
+          const float Bp0 = Bp + fac0 * cd0;
+          const float T1 = T0 * ra1;
+          const float fac1 = a1 * T1;
+          const float va1 = T1 * cd1 - ra1 * Bp0;
+          T = T1;
+          Bp = Bp0 + fac1 * cd1;
+          if (ok0) {
+            float w = (opv0 <= GSL_ALPHA_MAX) ? vis0 * va0 : 0.f;
+            int cc = j - tiny_origin(p0.x, p1.w), rr = i - tiny_origin(p0.y, p1.w);
+            if ((unsigned)cc < 4u && (unsigned)rr < 4u)
+              trec[(size_t)sb.id[t0] * 16 + rr * 4 + cc] = make_float2(w, fac0);
+            else if (flags)
+              flags[0] = 1;  // sticky: the splat outgrew its 4x4 slab (r_cull >= 2 px); polled by the host
+          }
+          if (ok1) {
+            float w = (opv1 <= GSL_ALPHA_MAX) ? vis1 * va1 : 0.f;
+            int cc = j - tiny_origin(u0.x, u1.w), rr = i - tiny_origin(u0.y, u1.w);
+            if ((unsigned)cc < 4u && (unsigned)rr < 4u)
+              trec[(size_t)sb.id[t1] * 16 + rr * 4 + cc] = make_float2(w, fac1);
+            else if (flags)
+              flags[0] = 1;
           }
         }
       }

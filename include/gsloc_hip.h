@@ -42,6 +42,9 @@ typedef enum gsl_status {
 const char* gsl_version(void);
 /* Text for a gsl_status. */
 const char* gsl_status_string(int status);
+/* Diagnostics (tests): fill the LDS of every CU with `pattern` (e.g. 0xFFFFFFFF, a NaN), to show that no kernel of the
+ * library reads LDS it has not written. */
+int gsl_dev_poison_lds(uint32_t pattern, void* stream);
 /* ---- projection: gsplat.fully_fused_projection fwd/bwd (IDX:14351, IDX:14270) ----
  * One camera.  viewmat[16] world->camera row-major, K[9] intrinsics, both on device.
  * Outputs for culled Gaussians: radii = 0, other outputs 0.

@@ -106,3 +106,78 @@ def test_no_write_outside_buffers_with_a_long_tile_list():
     ctx.check_capacity()
     _check(homes)
     assert torch.isfinite(ctx.v_viewmat).all()
+
+
+@pytest.mark.parametrize("sigma_px,mode,bwd", [(1.0, "RGB+ED", "auto"), (1.0, "ED", "auto"), (0.0, "RGB+ED", "tiny"),
+                                               (0.0, "ED", "tiny"), (1.0, "RGB", "auto")])
+def test_results_do_not_depend_on_stale_lds(sigma_px, mode, bwd, monkeypatch):
+    """The compositing kernels' straight-line trips let a lane without a candidate read SOME staged slot and multiply
+    it by an exact zero -- so every slot must hold finite numbers written in the same batch.  LDS is filled with NaNs
+    (then with +Inf, then with zeros) by gsl_dev_poison_lds before each pass: the images must be bit-identical and the
+    gradients finite and equal up to the order of the float atomics."""
+    from gsplatloc_amd._lib import check, current_stream, load_library
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    dev = torch.device("cuda")
+    monkeypatch.setenv("GSLOC_BWD", bwd)
+    N, W, H = 40_003, 333, 217
+    sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev)
+    viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    ctx = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, sc["K"].contiguous())
+    ctx.calibrate(*inp)
+    assert ctx.tiny == (bwd == "tiny")
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(H, W, ctx.D, generator=g).to(dev)
+    va = torch.randn(H, W, 1, generator=g).to(dev)
+    lib = load_library()
+    out = []
+    for pattern in (0xFFFFFFFF, 0x7F800000, 0):
+        check(lib.gsl_dev_poison_lds(pattern, current_stream()), "gsl_dev_poison_lds")
+        ctx.forward(*inp)
+        check(lib.gsl_dev_poison_lds(pattern, current_stream()), "gsl_dev_poison_lds")
+        grads = ctx.backward(v, va, full=True)
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        out.append((ctx.render.clone(), ctx.alphas.clone(), {k: t.clone() for k, t in grads.items() if t is not None}))
+    for r, a, gr in out[:2]:
+        assert torch.equal(r, out[2][0]) and torch.equal(a, out[2][1])
+        for k, t in gr.items():
+            assert torch.isfinite(t).all(), k
+            if k == "quats":  # (isotropic splats: this gradient is cancellation noise around 1e-7, atomics order and all)
+                continue
+            scale = float(out[2][2][k].abs().max()) + 1e-30
+            assert float((t - out[2][2][k]).abs().max()) <= 1e-4 * scale, k
+
+
+def test_long_list_results_do_not_depend_on_stale_lds():
+    """The same with a pile (long-list split: k_long_fwd passes A / B, the segment backward)."""
+    from gsplatloc_amd._lib import check, current_stream, load_library
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=1, holes=True, device=dev, pile=True)
+    N = sc["means"].shape[0]
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
+    ctx.calibrate(*inp)
+    assert ctx.long_min > 0
+    g = torch.Generator().manual_seed(5)
+    v = torch.randn(H, W, ctx.D, generator=g).to(dev)
+    va = torch.randn(H, W, 1, generator=g).to(dev)
+    lib = load_library()
+    out = []
+    for pattern in (0xFFFFFFFF, 0):
+        check(lib.gsl_dev_poison_lds(pattern, current_stream()), "gsl_dev_poison_lds")
+        ctx.forward(*inp)
+        check(lib.gsl_dev_poison_lds(pattern, current_stream()), "gsl_dev_poison_lds")
+        gv = ctx.backward(v, va, full=False)["viewmat"].clone()
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        out.append((ctx.render.clone(), ctx.alphas.clone(), gv))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert torch.isfinite(out[0][2]).all()
+    assert float((out[0][2] - out[1][2]).abs().max()) <= 1e-4 * float(out[1][2].abs().max())
