@@ -1,6 +1,7 @@
 """One-GPU estimate of the tile-strip strong-scaling curve of bench.py: for world = 1,2,4,8 build every
 rank's strip context in turn on this GPU, replay its graph, and report max-over-ranks step time
-(excludes the 16-float all-reduce).  python scripts/strip_scaling.py [sigma_px] [order]"""
+(excludes the 16-float all-reduce).  python scripts/strip_scaling.py [sigma_px] [order] [R|X]
+(X: 5 M Gaussians, 1920x1080, fp16-staged records -- BASELINE.json configs[4])"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gsplatloc_amd.context import RenderContext, time_stages
@@ -9,7 +10,9 @@ from gsplatloc_amd.synthetic import random_scene, perturbed_pose
 
 sig = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 order = sys.argv[2] if len(sys.argv) > 2 else "random"
-N, W, H = 1_000_000, 1200, 680
+size = sys.argv[3] if len(sys.argv) > 3 else "R"
+N, W, H = (5_000_000, 1920, 1080) if size == "X" else (1_000_000, 1200, 680)
+staging = "fp16" if size == "X" else "fp32"
 dev = torch.device("cuda")
 sc = random_scene(N, W, H, sigma_px=sig, device=dev, order=order)
 viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
@@ -30,7 +33,8 @@ for world in (1, 2, 4, 8):
         else:
             loc = sc
         n = loc["means"].shape[0]
-        ctx = RenderContext(n, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=True)
+        ctx = RenderContext(n, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=True,
+                            staging=staging)
         inp = (loc["means"], loc["quats"], loc["scales"], loc["opacities"], loc["sh"], viewmat, K)
         ctx.calibrate(*inp)
         def step():
