@@ -9,6 +9,7 @@
 // composite key makes the result independent of scatter order and identical to a stable
 // global sort of the gsplat key.  Wave64 lanes that hit the same tile are merged with a
 // ballot so hot tiles see one atomic per wave instead of 64.
+#include <cstdlib>
 #include "gsloc_common.h"
 
 namespace gsl {
@@ -711,6 +712,128 @@ __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ t
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One tile per 256-thread workgroup (lists of a few hundred to 2048 keys).  One wave sorting a 1 460-key list in registers
+// is 60 us of pure latency when a strip has fewer tiles than the chip has SIMDs (8 strips of workload X), and a bitonic
+// network over the padded power of two does n log^2 n work.  Here every wave sorts a quarter of the list in registers
+// (wave_sort_regs), the four runs go to LDS and two merge-path passes (every thread merges its 2^LK outputs) finish the
+// job: a third of the compare-exchanges, a quarter of the critical path.  Same result: the keys are unique.
+// ------------------------------------------------------------------------------------------------
+template <int LK>
+__device__ __forceinline__ void wg_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int tid,
+                                             uint64_t* __restrict__ lds, uint64_t* __restrict__ keys_out,
+                                             int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
+                                             int64_t cam_enc) {
+  constexpr int KPT = 1 << LK, RUN = 64 * KPT;
+  const int lane = tid & 63, wv = tid >> 6;
+  uint64_t k[KPT];
+  const int e0 = wv * RUN + lane * KPT;
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) k[r] = (e0 + r < n) ? src[e0 + r] : ~0ull;
+  wave_sort_regs<LK>(k, lane);
+  uint64_t* bufA = lds;
+  uint64_t* bufB = lds + 4 * RUN;
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) bufA[e0 + r] = k[r];
+  __syncthreads();
+  {  // runs (0, 1) and (2, 3) -> two runs of 2 RUN in bufB
+    const int p = tid >> 7, l = tid & 127;
+    const uint64_t* A = bufA + p * 2 * RUN;
+    const uint64_t* B = A + RUN;
+    const int d0 = l * KPT;
+    int ia = merge_diag(A, RUN, B, RUN, d0), ib = d0 - ia;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      uint64_t v;
+      if (ib >= RUN || (ia < RUN && A[ia] <= B[ib])) v = A[ia++];
+      else v = B[ib++];
+      bufB[p * 2 * RUN + d0 + q] = v;
+    }
+  }
+  __syncthreads();
+  {  // the two runs of 2 RUN -> the result
+    const uint64_t* A = bufB;
+    const uint64_t* B = bufB + 2 * RUN;
+    const int d0 = tid * KPT;
+    if (d0 < n) {
+      int ia = merge_diag(A, 2 * RUN, B, 2 * RUN, d0), ib = d0 - ia;
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) {
+        uint64_t v;
+        if (ib >= 2 * RUN || (ia < 2 * RUN && A[ia] <= B[ib])) v = A[ia++];
+        else v = B[ib++];
+        if (d0 + q < n) {
+          flatten_ids[s + d0 + q] = (int32_t)(uint32_t)v;
+          if (isect_ids) isect_ids[s + d0 + q] = cam_enc | ((int64_t)t << 32) | (int64_t)(v >> 32);
+          if (keys_out) keys_out[s + d0 + q] = v;
+        }
+      }
+    }
+  }
+}
+
+// Same contract as k_tile_sort (offsets from the counters in binned mode, overflow flags, long lists left to
+// gsl_long_sort), one tile per workgroup.
+__global__ __launch_bounds__(256) void k_tile_sort_wg(int32_t* __restrict__ tile_offsets, int tile_begin,
+                                                      int n_strip_tiles, long long capacity,
+                                                      uint64_t* __restrict__ keys, int32_t* __restrict__ flatten_ids,
+                                                      int64_t* __restrict__ isect_ids, int64_t cam_enc,
+                                                      int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap,
+                                                      const int32_t* __restrict__ counts, int32_t* __restrict__ n_isects,
+                                                      int32_t* __restrict__ flags, int long_min) {
+  __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
+  __shared__ int s_scan[5];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int t = tile_begin + blockIdx.x;
+  long long s, e;
+  if (counts) {
+    int acc = 0;
+    for (int i = tid; i < t; i += 256) acc += min(counts[i], bin_cap);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) s_scan[wv] = acc;
+    if (tid == 0) {
+      int c_own = counts[t];
+      s_scan[4] = min(c_own, bin_cap);
+      if (c_own > bin_cap && flags) { flags[1] = 1; atomicMax(&flags[2], c_own); }
+    }
+    __syncthreads();
+    s = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    e = s + s_scan[4];
+    if (tid == 0) {
+      tile_offsets[t] = (int32_t)s;
+      if ((int)blockIdx.x == n_strip_tiles - 1) {
+        tile_offsets[t + 1] = (int32_t)e;
+        if (n_isects) n_isects[0] = (int32_t)e;
+      }
+    }
+  } else {
+    s = tile_offsets[t];
+    e = tile_offsets[t + 1];
+  }
+  if (e > capacity) e = capacity;
+  int n = (int)max(e - s, (long long)0);
+  if (bins && n > bin_cap) n = bin_cap;
+  if (n == 0) return;
+  uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
+  uint64_t* kout = write_sorted_keys ? keys : nullptr;
+  if (n <= 1024) {
+    wg_sort_tile<2>(src, n, s, t, tid, skeys, kout, flatten_ids, isect_ids, cam_enc);
+  } else if (n <= 2048) {
+    wg_sort_tile<3>(src, n, s, t, tid, skeys, kout, flatten_ids, isect_ids, cam_enc);
+  } else {
+    if (long_min > 0 && bins && n > long_min) return;  // sorted by several workgroups: gsl_long_sort
+    bitonic_sort_long(src, n, skeys, tid);
+    for (int i = tid; i < n; i += 256) {
+      uint64_t k = src[i];
+      flatten_ids[s + i] = (int32_t)(uint32_t)k;
+      if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
+      if (write_sorted_keys && bins) keys[s + i] = k;
+    }
+  }
+}
+
 }  // namespace gsl
 
 extern "C" size_t gsl_isect_ws_bytes(int n_tiles) {
@@ -775,17 +898,19 @@ extern "C" int gsl_isect_fill(const float* means2d, const int32_t* radii, const 
                        cam_enc, stream);
 }
 
+extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
+                                  uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
+                                  int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
+                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles, void* stream);
+
 extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                              uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                              void* stream) {
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     const_cast<int32_t*>(tile_offsets), tile_begin, n_strip_tiles, (long long)capacity, sort_keys,
-                     flatten_ids, isect_ids, cam_enc, 0, (uint64_t*)nullptr, 0, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, 0);
-  GSL_CHECK_LAUNCH();
-  return GSL_OK;
+  return gsl_tile_sort_keys(const_cast<int32_t*>(tile_offsets), tile_begin, n_strip_tiles, capacity, sort_keys, flatten_ids,
+                            isect_ids, cam_enc, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 // gsl_tile_sort that can also leave the sorted (depth bits, id) keys in sort_keys and read the unsorted keys from
@@ -793,14 +918,28 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
 extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                                   int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
-                                  int32_t* n_isects, int32_t* flags, int long_min, void* stream) {
+                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles, void* stream) {
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (counts && (!bins || tile_begin != 0)) return GSL_ERR_BAD_ARG;  // the scan runs over all tiles, bins only
   if (n_strip_tiles == 0 || (capacity == 0 && !counts)) return GSL_OK;
   if (capacity > 0 && (!sort_keys || !flatten_ids)) return GSL_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
-                     tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
-                     write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min);
+  // lists of several hundred keys: one tile per workgroup (waves sort quarters, merged in LDS); short lists: one per wave
+  // (occupied_tiles: the tiles that can hold entries -- a strip's, when the launch runs over all tiles of the image)
+  const int occ = occupied_tiles > 0 ? occupied_tiles : n_strip_tiles;
+  const long long mean_list = capacity / (long long)occ;
+  const char* force = getenv("GSL_DEV_TILE_SORT");  // dev / test switch: "wave" / "wg"
+  // (a latency matter: with more tiles than the chip has room for wave sorts at once, one tile per wave keeps more
+  // lists in flight and is as fast or faster -- X: 159 against 169 us; with a strip's few hundred tiles the workgroup
+  // kernel's shorter critical path decides)
+  const bool wg = force ? force[1] == 'g' : (mean_list > 320 && occ <= 2048);
+  if (wg)
+    hipLaunchKernelGGL(gsl::k_tile_sort_wg, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                       tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
+                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min);
+  else
+    hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                       tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
+                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -971,7 +971,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
 extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                                   int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
-                                  int32_t* n_isects, int32_t* flags, int long_min, void* stream);
+                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles, void* stream);
 
 extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0, int ty1,
                              int tile_n_bits, int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
@@ -990,7 +990,7 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
     if (capacity > 0 && (!sort_keys || !flatten_ids)) return GSL_ERR_BAD_ARG;
     return gsl_tile_sort_keys(tile_offsets, 0, n_tiles, capacity, sort_keys, flatten_ids, isect_ids, 0,
                               write_sorted_keys, (uint64_t*)bins, bin_cap, (const int32_t*)ws, n_isects, flags,
-                              write_sorted_keys ? 0 : long_min, stream);
+                              write_sorted_keys ? 0 : long_min, nst, stream);
   }
   if (N == 0 || capacity == 0 || nst == 0) return GSL_OK;
   if (!Q0 || !radii || !sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
@@ -1002,7 +1002,7 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
                      tile_offsets, cursors, (long long)capacity, sort_keys);
   GSL_CHECK_LAUNCH();
   return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
-                            write_sorted_keys, nullptr, 0, nullptr, nullptr, nullptr, 0, stream);
+                            write_sorted_keys, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 // defined in raster_g16.hip

@@ -141,11 +141,15 @@ def test_binning_multi_camera_and_empty():
     assert off.shape == (2, th, tw) and int(off.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("N", [200, 256, 257, 700, 1024, 1025, 2048, 2049, 3000, 4097, 8192, 12289, 20000, 70001])
-def test_binning_long_tile_list_uses_global_sort(N):
+@pytest.mark.parametrize("kernel", ["wave", "wg"])
+@pytest.mark.parametrize("N", [5, 63, 200, 256, 257, 700, 1024, 1025, 2048, 2049, 3000, 4097, 8192, 12289, 20000, 70001])
+def test_binning_long_tile_list_uses_global_sort(N, kernel, monkeypatch):
     """One tile list of every size class of the sort: a wave's registers (4, 8, 16, 32 keys per lane, at and around the
-    class boundaries), and beyond 2048 entries the block-wise long-list sort with whole and partial last blocks."""
+    class boundaries), and beyond 2048 entries the block-wise long-list sort with whole and partial last blocks -- by
+    the one-tile-per-wave kernel and by the one-tile-per-workgroup kernel (quarters sorted by the waves, merged in LDS;
+    GSL_DEV_TILE_SORT forces either, the library picks by the mean list length)."""
     A = _gpu()
+    monkeypatch.setenv("GSL_DEV_TILE_SORT", kernel)
     g = torch.Generator().manual_seed(3)
     m2 = (torch.rand(1, N, 2, generator=g) * 14 + 1).float()
     r = torch.full((1, N), 1, dtype=torch.int32)
@@ -404,13 +408,15 @@ def test_tiny_splat_backward_matches_general_backward(mode, full, monkeypatch):
             mostly_close(out["tiny"][k], out["general"][k], rtol=1e-3, atol=1e-5 * scale, max_bad_frac=1e-3, what=k)
 
 
-def test_binned_projection_gives_the_lists_of_two_pass_binning():
-    """RenderContext bins directly from the projection kernel once calibrate() knows the tile sizes (no scatter pass);
+@pytest.mark.parametrize("kernel", ["wave", "wg"])
+def test_binned_projection_gives_the_lists_of_two_pass_binning(kernel, monkeypatch):
+    """(Both tile-sort kernels.)  RenderContext bins directly from the projection kernel once calibrate() knows the tile sizes (no scatter pass);
     the sorted lists, offsets, render and gradients are those of the count -> scan -> scatter path, bit for bit
     (integer work) -- also for a strip, for the deterministic mode's sorted keys, and when a pose change makes the
     lists longer than at calibration.  A tile that outgrows its bin is flagged, never silently truncated."""
     _gpu()
     from gsplatloc_amd.context import RenderContext
+    monkeypatch.setenv("GSL_DEV_TILE_SORT", kernel)
     W, H, N = 260, 200, 40000
     sc = _scene32(N, W, H, sigma_px=1.3, opacity=(0.3, 1.0))
     sh = sh_from_rgb(sc["rgbs"]).to(DEV)
@@ -695,13 +701,16 @@ def test_legacy_pair_on_the_gpu():
     assert em < 1e-3, em  # per-Gaussian gradients: largest entry of a single splat, float32 against float64
 
 
+@pytest.mark.parametrize("kernel", ["wave", "wg"])
 @pytest.mark.parametrize("seed", range(4))
-def test_hip_binning_on_adversarial_inputs(seed):
+def test_hip_binning_on_adversarial_inputs(seed, kernel, monkeypatch):
     """The HIP tile binning (stage operators) on the inputs of tests/test_c_oracle.py's adversarial case: centres
     outside the image, radii larger than the image, exact tile boundaries, equal depths.  Bit-exact against the
-    oracle."""
+    oracle, with either tile-sort kernel."""
     import gsplatloc_amd as A
     from oracle import gsplat_oracle as G
+
+    monkeypatch.setenv("GSL_DEV_TILE_SORT", kernel)
 
     g = torch.Generator().manual_seed(100 + seed)
     N, W, H, ts = 400, 150 + 7 * seed, 90 + 5 * seed, 16
