@@ -47,41 +47,42 @@ class RGBDFrame:
         return np.stack([x, y, z], axis=-1).reshape(-1, 3)
 
 
+def _camera_block(path: Path) -> dict:
+    """The "camera" mapping of a json / yaml camera file."""
+    text = path.read_text()
+    if path.suffix.lower() in (".yaml", ".yml"):
+        import yaml
+
+        return dict(yaml.safe_load(text)["camera"])
+    return dict(json.loads(text)["camera"])
+
+
 class BaseDataset(Sequence):
-    """dataset.py:17-76: camera config (json/yaml), optional crop_edge, K."""
+    """Camera description shared by the readers (role of dataset.py:17-76): depth scale, optional distortion,
+    optional crop_edge (the intrinsics and the image size shrink with the cropped border), K."""
 
     def __init__(self, input_folder: str, cfg_file: str):
-        assert Path(input_folder).exists(), f"Path {input_folder} does not exist."
-        assert Path(cfg_file).exists(), f"Path {cfg_file} does not exist."
-        self.input_folder = Path(input_folder)
-        cfg_path = Path(cfg_file)
-        with open(cfg_path) as f:
-            if cfg_path.suffix in (".yaml", ".yml"):
-                import yaml
-                cfg = yaml.safe_load(f)
-            else:
-                cfg = json.load(f)
-        self.cfg = cfg["camera"]
-        self.scale = self.cfg["scale"]
-        self.distortion = np.array(self.cfg["distortion"]) if "distortion" in self.cfg else None
-        self.crop_edge = self.cfg.get("crop_edge", 0)
-        if self.crop_edge:
-            self.cfg["h"] -= 2 * self.crop_edge
-            self.cfg["w"] -= 2 * self.crop_edge
-            self.cfg["cx"] -= self.crop_edge
-            self.cfg["cy"] -= self.crop_edge
-        self.K = np.eye(3)
-        self.K[0, 0], self.K[1, 1], self.K[0, 2], self.K[1, 2] = (self.cfg["fx"], self.cfg["fy"], self.cfg["cx"],
-                                                                   self.cfg["cy"])
+        root, cam_file = Path(input_folder), Path(cfg_file)
+        for what in (root, cam_file):
+            if not what.exists():
+                raise AssertionError(f"Path {what} does not exist.")
+        self.input_folder = root
+        cam = _camera_block(cam_file)
+        border = int(cam.get("crop_edge", 0))
+        if border:  # a border of `border` pixels is cut off every side: principal point and size move with it
+            cam.update(h=cam["h"] - 2 * border, w=cam["w"] - 2 * border, cx=cam["cx"] - border, cy=cam["cy"] - border)
+        self.cfg, self.crop_edge, self.scale = cam, border, cam["scale"]
+        self.distortion = np.asarray(cam["distortion"]) if "distortion" in cam else None
+        self.K = np.array([[cam["fx"], 0.0, cam["cx"]], [0.0, cam["fy"], cam["cy"]], [0.0, 0.0, 1.0]])
 
     def __getitem__(self, index):
-        if isinstance(index, int):
-            if index >= len(self) or index < 0:
-                raise ValueError(f"Index {index} out of range (0 to {len(self) - 1})")
-            return self._get_one(index)
-        elif isinstance(index, slice):
+        if isinstance(index, slice):
             return [self._get_one(i) for i in range(*index.indices(len(self)))]
-        raise TypeError(f"index must be int or slice but now is {type(index)}")
+        if not isinstance(index, (int, np.integer)):
+            raise TypeError(f"frames are addressed by int or slice, not {type(index).__name__}")
+        if not 0 <= index < len(self):  # (ValueError, as the reference's readers raise: callers iterate until it)
+            raise ValueError(f"frame {index} does not exist: the sequence has {len(self)} frames")
+        return self._get_one(int(index))
 
     def _crop(self, a: np.ndarray) -> np.ndarray:
         c = self.crop_edge
@@ -94,25 +95,25 @@ class Replica(BaseDataset):
     def __init__(self, name: str = "room0", *, input_folder: Path | str = "datasets/Replica",
                  cfg_file: Path | str | None = None):
         self.name = name
-        input_folder = Path(input_folder)
-        cfg_file = Path(cfg_file) if cfg_file is not None else input_folder / "cam_params.json"
-        super().__init__((input_folder / name).as_posix(), cfg_file.as_posix())
+        base = Path(input_folder)
+        cam_file = base / "cam_params.json" if cfg_file is None else Path(cfg_file)
+        super().__init__(str(base / name), str(cam_file))
         self._color_paths = sorted(self.input_folder.rglob("frame*.jpg"), key=_natural_key)
         self._depth_paths = sorted(self.input_folder.rglob("depth*.png"), key=_natural_key)
-        if len(self._color_paths) == 0 or len(self._depth_paths) == 0:
-            raise FileNotFoundError(f"No images found in {self.input_folder}. Please check the path.")
+        if not self._color_paths or not self._depth_paths:
+            raise FileNotFoundError(f"no frame*.jpg / depth*.png under {self.input_folder}")
         if len(self._color_paths) != len(self._depth_paths):
-            raise ValueError(f"Number of color and depth images do not match in {self.input_folder}.")
-        self._num_img = len(self._color_paths)
-        with open(self.input_folder / "traj.txt") as f:
-            lines = f.readlines()
-        self._poses = [np.array(list(map(float, lines[i].split()))).reshape(4, 4) for i in range(self._num_img)]
+            raise ValueError(f"{len(self._color_paths)} colour images but {len(self._depth_paths)} depth images "
+                             f"under {self.input_folder}")
+        # traj.txt: one row-major 4x4 camera-to-world matrix per line
+        rows = np.loadtxt(self.input_folder / "traj.txt", dtype=np.float64, ndmin=2)
+        self._poses = [row.reshape(4, 4) for row in rows[: len(self._color_paths)]]
 
     def __str__(self):
         return f"Replica dataset: {self.name}\n in {self.input_folder}"
 
     def __len__(self):
-        return self._num_img
+        return len(self._color_paths)
 
     def _get_one(self, index: int) -> RGBDFrame:
         depth = _imread(self._depth_paths[index]).astype(np.float64) / self.scale
@@ -120,23 +121,43 @@ class Replica(BaseDataset):
         return RGBDFrame(rgb, depth, self.K, self._poses[index])
 
 
+def _nearest(stamps: np.ndarray, t: np.ndarray):
+    """Per query time t[i]: index of the closest entry of `stamps` (the first one on a tie) and its distance."""
+    gap = np.abs(stamps[None, :] - t[:, None])
+    idx = gap.argmin(axis=1)
+    return idx, gap[np.arange(len(t)), idx]
+
+
+def _tum_pose(row: np.ndarray) -> np.ndarray:
+    """TUM ground-truth row (tx ty tz qx qy qz qw) -> 4x4 camera-to-world."""
+    x, y, z, w = row[3:7] / np.linalg.norm(row[3:7])
+    c2w = np.eye(4)
+    c2w[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+    c2w[:3, 3] = row[:3]
+    return c2w
+
+
 class TUM(BaseDataset):
-    """dataset.py:163-321: timestamp association (max_dt 0.08 s), frame-rate thinning, poses relative to
-    the first frame, crop_edge."""
+    """Role of dataset.py:163-321: every colour image is paired with the depth image and the ground-truth pose closest
+    in time (both within 0.08 s, else the image is dropped); the sequence is thinned to at most `frame_rate` frames
+    per second; poses are expressed relative to the first kept frame; crop_edge from the camera file."""
+
+    MAX_DT = 0.08
 
     def __init__(self, name: str = "freiburg1_desk", *, input_folder: Path | str = "datasets/TUM",
                  frame_rate: int = 32):
         self.name = "rgbd_dataset_" + name
         data_dir = Path(input_folder) / self.name
-        super().__init__(data_dir.as_posix(), (data_dir / "cam_params.json").as_posix())
+        super().__init__(str(data_dir), str(data_dir / "cam_params.json"))
         self._color_paths, self._depth_paths, self._poses = self._load_tum_data(frame_rate)
-        self._num_img = len(self._color_paths)
 
     def __str__(self):
         return f"TUM dataset: {self.name}\n in {self.input_folder}"
 
     def __len__(self):
-        return self._num_img
+        return len(self._color_paths)
 
     def _get_one(self, index: int) -> RGBDFrame:
         depth = self._crop(_imread(self._depth_paths[index]).astype(np.float32)) / self.scale
@@ -144,67 +165,36 @@ class TUM(BaseDataset):
         return RGBDFrame(rgb, depth, self.K, self._poses[index])
 
     @staticmethod
-    def _parse_list(filepath: Path, skiprows: int = 0) -> np.ndarray:
-        return np.loadtxt(filepath, delimiter=" ", dtype=np.str_, skiprows=skiprows, comments="#")
-
-    @staticmethod
-    def _associate_frames(tstamp_image, tstamp_depth, tstamp_pose, max_dt: float = 0.08):
-        associations = []
-        for i, t in enumerate(tstamp_image):
-            j = int(np.argmin(np.abs(tstamp_depth - t)))
-            k = int(np.argmin(np.abs(tstamp_pose - t)))
-            if np.abs(tstamp_depth[j] - t) < max_dt and np.abs(tstamp_pose[k] - t) < max_dt:
-                associations.append((i, j, k))
-        return associations
-
-    @staticmethod
-    def _get_frame_indices(associations, tstamp_image, frame_rate: int):
-        indices = [0]
-        for i in range(1, len(associations)):
-            if tstamp_image[associations[i][0]] - tstamp_image[associations[indices[-1]][0]] > 1.0 / frame_rate:
-                indices.append(i)
-        return indices
-
-    @staticmethod
-    def _pose_matrix_from_quaternion(pvec: np.ndarray) -> np.ndarray:
-        from scipy.spatial.transform import Rotation
-
-        pose = np.eye(4)
-        pose[:3, :3] = Rotation.from_quat(pvec[3:]).as_matrix()
-        pose[:3, 3] = pvec[:3]
-        return pose
+    def _table(path: Path, header_rows: int = 0) -> np.ndarray:
+        """A TUM text table ("# comment" lines, blank-separated columns) as an array of strings."""
+        return np.loadtxt(path, dtype=np.str_, comments="#", skiprows=header_rows, ndmin=2)
 
     def _load_tum_data(self, frame_rate: int):
         d = self.input_folder
-        pose_list = d / ("groundtruth.txt" if (d / "groundtruth.txt").is_file() else "pose.txt")
-        image_data = self._parse_list(d / "rgb.txt")
-        depth_data = self._parse_list(d / "depth.txt")
-        pose_data = self._parse_list(pose_list, skiprows=1)
-        pose_vecs = pose_data[:, 1:].astype(np.float64)
-        t_img, t_dep, t_pose = (a[:, 0].astype(np.float64) for a in (image_data, depth_data, pose_data))
-        associations = self._associate_frames(t_img, t_dep, t_pose)
-        color_paths, depth_paths, poses = [], [], []
-        inv_pose = None
-        for ix in self._get_frame_indices(associations, t_img, frame_rate):
-            i, j, k = associations[ix]
-            color_paths.append(d / image_data[i, 1])
-            depth_paths.append(d / depth_data[j, 1])
-            c2w = self._pose_matrix_from_quaternion(pose_vecs[k])
-            if inv_pose is None:
-                inv_pose = np.linalg.inv(c2w)
-                c2w = np.eye(4)
-            else:
-                c2w = inv_pose @ c2w
-            poses.append(c2w.astype(np.float32))
-        return color_paths, depth_paths, poses
+        truth = d / "groundtruth.txt"
+        images, depths = self._table(d / "rgb.txt"), self._table(d / "depth.txt")
+        track = self._table(truth if truth.is_file() else d / "pose.txt", header_rows=1)
+        t_img, t_dep, t_pose = (tab[:, 0].astype(np.float64) for tab in (images, depths, track))
+        j, dt_depth = _nearest(t_dep, t_img)
+        k, dt_pose = _nearest(t_pose, t_img)
+        paired = np.flatnonzero((dt_depth < self.MAX_DT) & (dt_pose < self.MAX_DT))
+        # thinning: a frame is kept when more than 1 / frame_rate seconds have passed since the last kept one
+        kept, last_t = [], None
+        for i in paired:
+            if last_t is None or t_img[i] - last_t > 1.0 / frame_rate:
+                kept.append(int(i))
+                last_t = t_img[i]
+        world = [_tum_pose(track[k[i], 1:8].astype(np.float64)) for i in kept]
+        to_first = np.linalg.inv(world[0]) if world else None
+        poses = [(np.eye(4) if n == 0 else to_first @ m).astype(np.float32) for n, m in enumerate(world)]
+        return [d / images[i, 1] for i in kept], [d / depths[j[i], 1] for i in kept], poses
 
 
 def get_data_set(name: Literal["TUM", "Replica"], room: str, **kw):
-    if name == "TUM":
-        return TUM(room, **kw)
-    elif name == "Replica":
-        return Replica(room, **kw)
-    raise ValueError("data set name should be in ['TUM,Replica']")
+    readers = {"TUM": TUM, "Replica": Replica}
+    if name not in readers:
+        raise ValueError(f"unknown data set {name!r}: one of {sorted(readers)}")
+    return readers[name](room, **kw)
 
 
 @dataclass

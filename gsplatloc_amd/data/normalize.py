@@ -7,33 +7,31 @@ from torch import Tensor
 def align_principle_axes(point_cloud: Tensor) -> Tensor:
     """normalize.py:8-50: median-centred PCA frame; eigenvectors by descending eigenvalue, first axis
     flipped if the frame is left-handed.  Returns the 4x4 world->normalised transform."""
-    centroid = torch.median(point_cloud, dim=0).values
-    cov = torch.cov((point_cloud - centroid).t())
-    eigenvalues, eigenvectors = torch.linalg.eigh(cov)
-    eigenvectors = eigenvectors[:, eigenvalues.argsort(descending=True)]
-    if torch.det(eigenvectors) < 0:
-        eigenvectors[:, 0] *= -1
-    R = eigenvectors.t()
+    centre = point_cloud.median(dim=0).values
+    spread, axes = torch.linalg.eigh(torch.cov((point_cloud - centre).T))  # ascending eigenvalues
+    axes = axes.flip(dims=(1,))  # largest spread first
+    if torch.linalg.det(axes) < 0:  # keep the frame right-handed
+        axes[:, 0].neg_()
     T = torch.eye(4, device=point_cloud.device, dtype=point_cloud.dtype)
-    T[:3, :3] = R
-    T[:3, 3] = -torch.mv(R, centroid)
+    T[:3, :3] = axes.T
+    T[:3, 3] = -(axes.T @ centre)
     return T
 
 
 @torch.no_grad()
 def transform_points(matrix: Tensor, points: Tensor) -> Tensor:
     """normalize.py:53-72."""
-    return torch.addmm(matrix[:3, 3], points, matrix[:3, :3].t())
+    return points @ matrix[:3, :3].T + matrix[:3, 3]
 
 
 @torch.no_grad()
 def transform_cameras(matrix: Tensor, c2w: Tensor):
     """normalize.py:75-104: T @ c2w, rotation re-normalised by the norm of its first row (returned as the
     scale factor; 1 for a rigid T)."""
-    transformed = torch.einsum("ki,nij->nkj", matrix, c2w)
-    scaling = torch.norm(transformed[:, 0, :3], p=2, dim=1, keepdim=True)
-    transformed[:, :3, :3] /= scaling.unsqueeze(-1)
-    return transformed, scaling
+    moved = matrix.unsqueeze(0) @ c2w
+    scale = moved[:, 0, :3].norm(dim=1, keepdim=True)
+    moved[:, :3, :3] = moved[:, :3, :3] / scale.unsqueeze(-1)
+    return moved, scale
 
 
 @torch.no_grad()

@@ -25,19 +25,18 @@ def _quaternion_to_rotation_matrix(quaternion: Tensor) -> Tensor:
 
 
 def rotation_6d_to_matrix(d6: Tensor) -> Tensor:
-    """transform.py:7-29 (Zhou et al. 6D rotation, Gram-Schmidt)."""
-    a1, a2 = d6[..., :3], d6[..., 3:]
-    b1 = F.normalize(a1, dim=-1)
-    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
-    b2 = F.normalize(b2, dim=-1)
-    b3 = torch.cross(b1, b2, dim=-1)
-    return torch.stack((b1, b2, b3), dim=-2)
+    """Role of transform.py:7-29 (Zhou et al.'s 6D rotation): the two 3-vectors of `d6` are orthonormalised
+    (Gram-Schmidt) into the first two ROWS of the matrix, the third row is their cross product."""
+    first, second = d6[..., 0:3], d6[..., 3:6]
+    row0 = first / first.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    second = second - row0 * (row0 * second).sum(dim=-1, keepdim=True)
+    row1 = second / second.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    return torch.stack([row0, row1, torch.linalg.cross(row0, row1, dim=-1)], dim=-2)
 
 
 def matrix_to_rotation_6d(matrix: Tensor) -> Tensor:
-    """transform.py:32-47."""
-    batch_dim = matrix.size()[:-2]
-    return matrix[..., :2, :].clone().reshape(batch_dim + (6,))
+    """Role of transform.py:32-47: the first two rows, flattened."""
+    return matrix[..., 0:2, :].flatten(start_dim=-2).clone()
 
 
 def quat_to_rotation_matrix(quaternion: Tensor) -> Tensor:
