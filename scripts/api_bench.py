@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 import gsplatloc_amd as A
 from gsplatloc_amd.synthetic import depth_frame_scene, random_scene, perturbed_pose
 
-def api(sc, V, W, H, full, n=50):
+def api(sc, V, W, H, full, n=400):
     def step():
         Vg = V.clone().requires_grad_()
         m = sc["means"].clone().requires_grad_(full)
@@ -14,12 +14,17 @@ def api(sc, V, W, H, full, n=50):
                                        colors=sc["sh"], sh_degree=1, viewmats=Vg[None], Ks=sc["K"][None], width=W, height=H,
                                        packed=False, render_mode="RGB+ED", near_plane=1e-2, far_plane=1e10)
         (rc[..., 3] * 0.5).sum().backward()
-    for _ in range(5): step()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / n * 1e3
+    for _ in range(50): step()  # context creation, calibration, clocks
+    best = 1e9
+    for _ in range(3):  # best of three windows of n calls (a 16-CPU share of a busy host: windows differ by 20 %)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(n): step()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t) / n * 1e3)
+    return best
 
+api(depth_frame_scene(640, 480, stride=3), depth_frame_scene(640, 480, stride=3)["viewmat"], 640, 480, True, n=100)  # (the
+# first measurement of a process reads 30 % high whatever it measures: library load, allocator, clocks)
 for name in ("S", "R"):
     if name == "S":
         sc = depth_frame_scene(640, 480, stride=3); W, H = 640, 480; V = sc["viewmat"]
