@@ -375,6 +375,14 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   __shared__ float vred[4][15];
   __shared__ float vtot[15];
   __shared__ float svm[16];
+  // the state thread 0 works on (pose, Adam moments, learning rates, best-so-far, ground truth, counters) is fetched by
+  // three groups of lanes while the rows are being summed: read one after the other by the lone thread these were
+  // a dozen dependent global loads of the 9 us this kernel takes
+  __shared__ float sF[32], sG[16];
+  __shared__ int sI[4];
+  if (threadIdx.x >= 64 && threadIdx.x < 96) sF[threadIdx.x - 64] = f[threadIdx.x - 64];
+  else if (threadIdx.x >= 96 && threadIdx.x < 112) sG[threadIdx.x - 96] = gt_c2w[threadIdx.x - 96];
+  else if (threadIdx.x >= 112 && threadIdx.x < 116) sI[threadIdx.x - 112] = istate[threadIdx.x - 112];
   if (vm_rows) {  // `viewmat` still holds the pose this iteration rendered with (thread 0 overwrites it at the very end)
     float v = reduce_viewmat_rows(vm_rows, n_vm, viewmat, Kmat, vred, vtot);
     if (threadIdx.x < 16) svm[threadIdx.x] = v;
@@ -395,19 +403,19 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  if (istate[2]) return;  // stopped: keep the state frozen (graph replays may still arrive)
-  int step = istate[0];
+  if (sI[2]) return;  // stopped: keep the state frozen (graph replays may still arrive)
+  int step = sI[0];
   float depth_loss = sums[0] * hp.inv_P, edge_loss = sums[1] * hp.inv_P;
   float total = hp.depth_w * depth_loss + hp.edge_w * edge_loss;
   if (hp.normal_w != 0.f) {  // sum of the row cosines: this rank's (normal_sum) or all ranks' (loss_sums_in[2])
     float cs = loss_sums_in ? loss_sums_in[2] : (normal_sum ? normal_sum[0] : 0.f);
     total += hp.normal_w * (1.f - cs * hp.inv_3H);
   }
-  float q[4] = {f[0], f[1], f[2], f[3]}, t[3] = {f[4], f[5], f[6]};
+  float q[4] = {sF[0], sF[1], sF[2], sF[3]}, t[3] = {sF[4], sF[5], sF[6]};
   float R[9], qh[4], qn;
   quat_to_R(q, R, qh, qn);
   // pose errors of the CURRENT pose vs ground truth (eval/utils.py:122-168)
-  float dt0 = t[0] - gt_c2w[3], dt1 = t[1] - gt_c2w[7], dt2 = t[2] - gt_c2w[11];
+  float dt0 = t[0] - sG[3], dt1 = t[1] - sG[7], dt2 = t[2] - sG[11];
   float eT = sqrtf(dt0 * dt0 + dt1 * dt1 + dt2 * dt2);
   // rotation angle of R_est R_gt^T (eval/utils.py:144-168 takes acos((trace - 1) / 2)).  In float32 that form
   // resolves angles only down to sqrt(2 * 6e-8) rad = 0.02 degrees -- the level of the reference's own AAE table --
@@ -415,22 +423,23 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   float fro = 0.f;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {
-      float d = R[i * 3 + j] - gt_c2w[i * 4 + j];
+      float d = R[i * 3 + j] - sG[i * 4 + j];
       fro += d * d;
     }
   float eR = 2.f * asinf(fminf(1.f, sqrtf(fro * 0.125f))) * 57.29577951308232f;
   f[28] = total; f[29] = eT; f[30] = eR;
   if (loss_hist && step < hp.max_steps) loss_hist[step] = total;
   if (hp.early_stop && step > hp.min_step) {
-    if (total < f[23]) {
+    if (total < sF[23]) {
       f[23] = total; f[24] = depth_loss; f[25] = edge_loss; f[26] = eT; f[27] = eR;
-      istate[1] = 0; istate[3] = step;
+      sI[1] = 0; istate[3] = step;
     } else {
-      istate[1] += 1;
+      sI[1] += 1;
     }
+    istate[1] = sI[1];
   }
   istate[0] = step + 1;
-  if (hp.early_stop && istate[1] >= hp.patience) { istate[2] = 1; return; }  // stop BEFORE the optimiser step
+  if (hp.early_stop && sI[1] >= hp.patience) { istate[2] = 1; return; }  // stop BEFORE the optimiser step
   if (step + 1 >= hp.max_steps) istate[2] = 1;  // last iteration still takes its optimiser step
   // ---- pose chain: viewmat = inv(c2w) => v_c2w = -V^T v_V V^T
   float V[16], vV[16];
@@ -476,10 +485,10 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   for (int k = 0; k < 7; ++k) {
     float p = (k < 4) ? q[k] : t[k - 4];
     float wd = (k < 4) ? hp.wd_quat : hp.wd_trans;
-    float lr = (k < 4) ? f[21] : f[22];
+    float lr = (k < 4) ? sF[21] : sF[22];
     float g = grad[k] + wd * p;
-    float m = f[7 + k] * hp.beta1 + (1.f - hp.beta1) * g;
-    float v = f[14 + k] * hp.beta2 + (1.f - hp.beta2) * g * g;
+    float m = sF[7 + k] * hp.beta1 + (1.f - hp.beta1) * g;
+    float v = sF[14 + k] * hp.beta2 + (1.f - hp.beta2) * g * g;
     f[7 + k] = m; f[14 + k] = v;
     float denom = sqrtf(v) / bc2s + hp.eps;
     p -= (lr / bc1) * (m / denom);
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(256) void k_pose_step(float* __restrict__ f, int* _
   }
   for (int k = 0; k < 4; ++k) f[k] = q[k];
   for (int k = 0; k < 3; ++k) f[4 + k] = t[k];
-  f[21] *= hp.gamma; f[22] *= hp.gamma;  // ExponentialLR
+  f[21] = sF[21] * hp.gamma; f[22] = sF[22] * hp.gamma;  // ExponentialLR
   write_pose(q, t, c2w, viewmat);
 }
 
