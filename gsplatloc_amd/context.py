@@ -330,13 +330,15 @@ class RenderContext:
                                                self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
                                                int(self.bins is not None), current_stream()), "gsl_long_raster_fwd")
 
-    def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor) -> None:
+    def _raster_bwd(self, v_render: Tensor, v_alphas: Tensor, tracking_loss=None) -> None:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,
                   self.ty0, self.ty1, ptr(self.offs), ptr(self.flatten_ids), self.capacity, ptr(self.render),
                   ptr(self.alphas), ptr(self.last_ids), ptr(v_render), ptr(v_alphas))
         if self.tiny:
+            loss = tracking_loss if tracking_loss is not None else (None, 0.0, 0.0, None)
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), self.row0, self.row1,
-                                               ptr(self.flags), self.long_min, current_stream()), "gsl_tiny_raster_bwd")
+                                               ptr(self.flags), self.long_min, ptr(loss[0]), float(loss[1]),
+                                               float(loss[2]), ptr(loss[3]), current_stream()), "gsl_tiny_raster_bwd")
             # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
@@ -414,16 +416,25 @@ class RenderContext:
             return "long tile lists outgrew their workspace"
         return None
 
+    def can_fuse_tracking_loss(self) -> bool:
+        """backward(tracking_loss=...) is available: tiny-splat backward over the whole frame, a depth channel."""
+        return bool(self.tiny and self.ty0 == 0 and self.ty1 == self.th and self.row0 == 0 and self.row1 >= self.H
+                    and self.D in (1, 4))
+
     def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None,
-                 reduce_viewmat: bool = True) -> Dict[str, Tensor]:
+                 reduce_viewmat: bool = True, tracking_loss=None) -> Dict[str, Tensor]:
         """vjp of the last forward.  Returns the context's gradient buffers: always ``viewmat``
         ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors.
         ``reduce_viewmat=False`` skips the last launch: the pose gradient stays as ``viewmat_rows()`` for
-        gsl_pose_step / gsl_pack_pose_reduce, which sum them in the same fixed order (``viewmat`` is then stale)."""
+        gsl_pose_step / gsl_pack_pose_reduce, which sum them in the same fixed order (``viewmat`` is then stale).
+        ``tracking_loss=(depth_gt [H,W], depth_lambda, edge_lambda, partials [tiles,2])`` (can_fuse_tracking_loss()):
+        the compositing backward computes gsl_tracking_loss's loss and gradient itself -- it WRITES v_render's depth
+        channel and the partials -- instead of reading an upstream gradient a separate launch left there."""
         assert self._inputs is not None, "forward() first"
         full = self.full_grads if full is None else full
         assert not full or self.full_grads, "context was built with full_grads=False"
-        self._raster_bwd(v_render, v_alphas)
+        assert tracking_loss is None or self.can_fuse_tracking_loss()
+        self._raster_bwd(v_render, v_alphas, tracking_loss)
         self._project_bwd(full, reduce_viewmat)
         out = {"viewmat": self.v_viewmat}
         if full:

@@ -22,6 +22,7 @@
 // Skipped candidates are exactly those the reference loop would `continue` over (alpha < 1/255), so the
 // per-pixel sequence of composited splats -- and therefore every output -- is unchanged.
 #include "gsloc_common.h"
+#include "loss_dev.h"
 
 namespace gsl {
 
@@ -507,17 +508,37 @@ struct TStage {
   int32_t id[256];
 };
 
-template <int D, bool ED>
+// LOSS (the tracker's iteration, whole frame, no normal term): the kernel computes its tile's share of the depth + edge
+// loss and the upstream gradient itself (loss_dev.h; the tile IS the loss kernel's 16x16 block) -- the separate loss
+// launch, 9 of the 90 us of an iteration at 102 k Gaussians, disappears.  v_render is still written (the long-list
+// backward and the tests read it) and partial[tile] as the loss kernel would.
+struct TinyLoss {
+  const float* gt;    // target depth [H,W]
+  float* partial;     // [tiles][2]
+  float* v_render;    // [H,W,D], channel D-1 written
+  float depth_w, edge_w, inv_P;
+};
+template <bool LOSS>
+struct TinyLossLds {
+  LossLds L;
+  float grad[16][16];
+};
+template <>
+struct TinyLossLds<false> {};
+
+template <int D, bool ED, bool LOSS>
 __global__ __launch_bounds__(256) void k_tiny_bwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float2* __restrict__ trec, float* __restrict__ vcT, int row0, int row1, int32_t* __restrict__ flags, int long_min) {
+    float2* __restrict__ trec, float* __restrict__ vcT, int row0, int row1, int32_t* __restrict__ flags, int long_min,
+    TinyLoss tl) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ TStage<D> sb;
   __shared__ int s_final[4];
+  __shared__ TinyLossLds<LOSS> sl;
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -526,13 +547,32 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
   float px = (float)j + 0.5f, py = (float)i + 0.5f;
   bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
   size_t pid = inside ? ((size_t)i * W + j) : 0;
+  if constexpr (LOSS) {
+    float g, l1, le;
+    bool has_pixel;
+    loss_block(sl.L, render, D, tl.gt, W, H, 0, H, H, tl.depth_w, tl.edge_w, tl.inv_P, txi * 16, tyi * 16, tid, g,
+               has_pixel, l1, le);
+    sl.grad[tid >> 4][tid & 15] = g;
+    if (has_pixel) tl.v_render[((size_t)(tyi * 16 + (tid >> 4)) * W + (txi * 16 + (tid & 15))) * D + (D - 1)] = g;
+    float s1 = wave_sum(l1), s2 = wave_sum(le);
+    if (lane == 0) { sl.L.red[wv][0] = s1; sl.L.red[wv][1] = s2; }
+    __syncthreads();
+    if (tid < 2)
+      tl.partial[2 * (size_t)tile + tid] = sl.L.red[0][tid] + sl.L.red[1][tid] + sl.L.red[2][tid] + sl.L.red[3][tid];
+  }
   float Aimg = inside ? alphas[pid] : 0.f;
   float T_final = 1.f - Aimg;
   int bin_final = inside ? last_ids[pid] : -1;
   float vc[D];
   float va = inside ? v_alphas[pid] : 0.f;
+  if constexpr (LOSS) {
 #pragma unroll
-  for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
+    for (int k = 0; k < D; ++k) vc[k] = 0.f;  // (the tracker's loss has no colour term)
+    if (inside) vc[D - 1] = sl.grad[(wv >> 1) * 8 + (lane >> 3)][(wv & 1) * 8 + (lane & 7)];
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) vc[k] = inside ? v_render[pid * D + k] : 0.f;
+  }
   if (ED && inside) {
     float dn = render[pid * D + (D - 1)];
     float vd = vc[D - 1];
@@ -669,7 +709,8 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
                                    const int32_t* flatten_ids, int64_t capacity, const float* render,
                                    const float* alphas, const int32_t* last_ids, const float* v_render,
                                    const float* v_alphas, float* trec, float* vcT, int row0, int row1,
-                                   int32_t* flags, int long_min, void* stream) {
+                                   int32_t* flags, int long_min, const float* loss_depth_gt, float depth_lambda,
+                                   float edge_lambda, float* loss_partials, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -677,19 +718,29 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
   if (!tile_offsets || !render || !alphas || !last_ids || !v_render || !v_alphas || !trec || !vcT)
     return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
+  // loss_depth_gt != NULL: the kernel computes the tracking loss of gsl_tracking_loss itself and WRITES v_render's
+  // depth channel and loss_partials[tiles][2]; whole frame only (the loss block of a tile is the tile)
+  const bool loss = loss_depth_gt != nullptr;
+  if (loss && (!loss_partials || ty0 != 0 || ty1 != tile_h || row0 != 0 || row1 < height ||
+               tile_w != (width + 15) / 16 || tile_h != (height + 15) / 16 || (channels != 1 && channels != 4)))
+    return GSL_ERR_BAD_ARG;
   if (ty0 == ty1) return GSL_OK;
   if (capacity > 0 && (!Q0 || !Q1 || !flatten_ids || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
-#define CALL_TB(DD, EE)                                                                                      \
-  hipLaunchKernelGGL((gsl::k_tiny_bwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,            \
+  gsl::TinyLoss tl{loss_depth_gt, loss_partials, const_cast<float*>(v_render), depth_lambda, edge_lambda,
+                   1.0f / ((float)width * (float)height)};
+#define CALL_TB(DD, EE, LL)                                                                                  \
+  hipLaunchKernelGGL((gsl::k_tiny_bwd<DD, EE, LL>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,        \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas,         \
-                     (float2*)trec, vcT, row0, row1, flags, long_min)
-  if (channels == 1) { if (ed) CALL_TB(1, true); else CALL_TB(1, false); }
-  else if (channels == 3) { CALL_TB(3, false); }
-  else if (channels == 4) { if (ed) CALL_TB(4, true); else CALL_TB(4, false); }
+                     (float2*)trec, vcT, row0, row1, flags, long_min, tl)
+#define CALL_TL(DD, EE) do { if (loss) CALL_TB(DD, EE, true); else CALL_TB(DD, EE, false); } while (0)
+  if (channels == 1) { if (ed) CALL_TL(1, true); else CALL_TL(1, false); }
+  else if (channels == 3) { CALL_TB(3, false, false); }
+  else if (channels == 4) { if (ed) CALL_TL(4, true); else CALL_TL(4, false); }
   else return GSL_ERR_BAD_ARG;
+#undef CALL_TL
 #undef CALL_TB
   GSL_CHECK_LAUNCH();
   return GSL_OK;

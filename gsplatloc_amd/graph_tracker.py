@@ -24,6 +24,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -127,6 +129,14 @@ class GraphTracker:
         st = current_stream()
         self.rc.forward(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K)
         edge_w = 1.0 - cfg.depth_lambda - cfg.normal_lambda
+        # one rank, no normal term, tiny-splat backward: the compositing backward computes the loss of its own tile and
+        # its gradient (gsl_tiny_raster_bwd(..., loss_depth_gt, ...)): one launch fewer per iteration
+        fuse = (self.group is None and self.normal_ws is None and self.rc.can_fuse_tracking_loss()
+                and os.environ.get("GSLOC_FUSE_LOSS", "1") != "0")
+        if fuse:
+            self.rc.backward(self.v_render, self.v_alphas, full=False, reduce_viewmat=False,
+                             tracking_loss=(self.gt_depth, cfg.depth_lambda, edge_w, self.partials))
+            return
         check(lib.gsl_tracking_loss(ptr(self.rc.render), self.rc.D, ptr(self.gt_depth), self.W, self.H, self.row0,
                                     self.row1, cfg.depth_lambda, edge_w, ptr(self.v_render), ptr(self.partials), None,
                                     ptr(self.loss_ws), self.loss_ws_bytes, st), "gsl_tracking_loss")

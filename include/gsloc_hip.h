@@ -292,7 +292,12 @@ int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int c
                         const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                         const float* render, const float* alphas, const int32_t* last_ids,
                         const float* v_render, const float* v_alphas, float* trec, float* vcT,
-                        int row0, int row1, int32_t* flags, int long_min, void* stream);
+                        int row0, int row1, int32_t* flags, int long_min, const float* loss_depth_gt,
+                        float depth_lambda, float edge_lambda, float* loss_partials, void* stream);
+/* loss_depth_gt != NULL (whole frame, channels 1 or 4): the kernel computes the tracking loss of gsl_tracking_loss for
+ * its tile itself -- the tile is that kernel's 16x16 block -- WRITES v_render's depth channel and
+ * loss_partials[tiles][2], and back-propagates from that gradient (v_render's other channels count as zero): the
+ * tracker's iteration then goes without the separate loss launch.  NULL: v_render is read as given. */
 
 /* ---- tracker tail: loss + pose update on device (csrc/tracker.hip) ----
  * Replaces the PyTorch/kornia glue of one iteration of GsplatLoc's Runner.train

@@ -245,6 +245,40 @@ def test_graph_tracker_early_stop():
     assert abs(res.steps - ref.steps) <= 2, (res.steps, ref.steps)  # fp32 ties in "loss < best" may shift the stop by an iteration
 
 
+@pytest.mark.parametrize("odd_size", [False, True])
+def test_loss_computed_inside_the_tiny_backward_matches_the_separate_loss_launch(odd_size, monkeypatch):
+    """One rank, no normal term, tiny-splat backward: gsl_tiny_raster_bwd(..., loss_depth_gt, ...) computes the tracking
+    loss of its tile and back-propagates from it -- same upstream gradient, same loss partials, same pose gradient rows
+    and the same trajectory as gsl_tracking_loss followed by the plain backward (GSLOC_FUSE_LOSS=0).  odd_size: an image
+    that is not a multiple of the tile size (partial tiles at the right and bottom borders)."""
+    M, fp, K, pts0, pts1, scales0, scales1 = _setup() if not odd_size else _setup(W=150, H=107)
+    from gsplatloc_amd.graph_tracker import GraphTracker
+    W, H = fp["W"], fp["H"]
+    src_depth = M.compute_depth_gt(pts1.to(DEV), fp["rgb"].to(DEV), K[None].to(DEV), torch.eye(4, device=DEV)[None], H, W)
+    cfg = M.TrackerConfig(max_steps=40, min_step=5, patience=1000)
+    frame = (pts0.to(DEV), fp["rgb"].to(DEV), scales0.to(DEV), src_depth, fp["c2w0"].to(DEV), fp["c2w1"].to(DEV), K.to(DEV))
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("GSLOC_FUSE_LOSS", fuse)
+        gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10, use_graph=False)
+        gt.load_frame(*frame)
+        assert gt.rc.tiny and gt.rc.can_fuse_tracking_loss()
+        gt._render_and_loss()  # one iteration's forward, loss, backward at the initial pose
+        torch.cuda.synchronize()
+        rows_ptr, n_rows = gt.rc.viewmat_rows()
+        one = dict(v=gt.v_render.clone(), partials=gt.partials.clone(), vcT=gt.rc.vcT.clone())
+        gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10)
+        gt.load_frame(*frame)
+        res = gt.run()
+        out[fuse] = dict(one=one, losses=torch.tensor(res.losses, dtype=torch.float64), c2w=res.final_c2w.clone())
+    a, b = out["0"], out["1"]
+    assert torch.equal(a["one"]["v"], b["one"]["v"])
+    assert torch.equal(a["one"]["partials"], b["one"]["partials"])
+    assert torch.equal(a["one"]["vcT"], b["one"]["vcT"])
+    assert torch.allclose(a["losses"], b["losses"], rtol=1e-6)
+    assert torch.allclose(a["c2w"], b["c2w"], rtol=0, atol=1e-6)
+
+
 def test_graph_tracker_recovers_from_overflows():
     """Neither a splat that outgrows the tiny backward nor an intersection list that outgrows its buffer nor a tile
     list that outgrows its bin costs the frame: all are flagged on the device, read at the poll, and the frame is re-run from its initial pose with the
