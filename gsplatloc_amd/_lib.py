@@ -43,9 +43,9 @@ _SIGNATURES = {
                               P, c_int, P, P, c_int, P]),
     "gsl_long_sort": (c_int, [P, c_int, c_int, c_int, c_int, c_int64, P, c_int, P, P, c_int, P, c_size_t, c_int, c_int, P]),
     "gsl_fused_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, c_int, c_int, P, P, P, P, c_int, P]),
+                                     P, P, P, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, P, P, P, c_int, c_int, P, P, P, P, c_int, P]),
+                                     P, P, P, P, P, P, c_int, c_int, P, P, P, P, c_int, P, P]),
     "gsl_long_ws_bytes": (c_size_t, [c_int]),
     "gsl_long_segment": (c_int, []),
     "gsl_long_sort_segment": (c_int, []),
@@ -73,7 +73,7 @@ _SIGNATURES = {
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P, P, P, P, c_int, c_int,
                                       c_int, c_int, c_int64, P, P, c_int, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                    P, P, P, P, P, P, P, c_int, c_int, P, c_int, P, c_float, c_float, P, P]),
+                                    P, P, P, P, P, P, P, c_int, c_int, P, c_int, P, c_float, c_float, P, P, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "gsl_isect_offsets": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),
     "gsl_rasterize_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P,

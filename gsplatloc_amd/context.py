@@ -34,8 +34,12 @@ class RenderContext:
                  K_sh: int = 4, device="cuda", eps2d: float = 0.3, near_plane: float = 0.01, far_plane: float = 1e10,
                  radius_clip: float = 0.0, antialiased: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
                  capacity: Optional[int] = None, full_grads: bool = True,
-                 pixel_rows: Optional[Tuple[int, int]] = None, staging: str = "fp32", deterministic: bool = False):
+                 pixel_rows: Optional[Tuple[int, int]] = None, staging: str = "fp32", deterministic: bool = False,
+                 sort_in_forward: bool = False):
         self.lib = load_library()
+        # sort_in_forward (callers whose every forward is followed by a backward: the tracker): the compositing forward
+        # sorts its own tile's bin -- no gsl_fused_bin launch -- whenever the frame allows it (sorts_in_forward())
+        self.sort_in_forward = bool(sort_in_forward)
         self.N, self.W, self.H = int(N), int(width), int(height)
         self.mode = render_mode
         self.D, self.ed = _MODES[render_mode]
@@ -236,6 +240,14 @@ class RenderContext:
         self.tiny = want
         self.flags[0] = 0
 
+    def sorts_in_forward(self) -> bool:
+        """The compositing forward does gsl_fused_bin's work for its own tile (gsl_fused_raster_fwd(..., sort_bins)):
+        asked for (sort_in_forward), binned projection, whole frame, every bin at most 2048 keys, no long lists, not the
+        deterministic mode.  The tile counters are then cleared by the compositing backward."""
+        return bool(self.sort_in_forward and self.bins is not None and 0 < self.bin_cap <= 2048 and self.long_min == 0
+                    and not self.deterministic and self.ty0 == 0 and self.ty1 == self.th
+                    and os.environ.get("GSLOC_SORT_IN_FORWARD", "1") != "0")
+
     def _screen_coherent_order(self) -> bool:
         """Do consecutive Gaussians land in the same or a neighbouring tile (a back-projected depth frame in pixel
         order: the reference's only input, /root/reference/src/my_gsplat/geometry.py:138-161)?  The tiny-splat backward
@@ -297,6 +309,8 @@ class RenderContext:
             current_stream()), "gsl_fused_project")
 
     def _bin(self) -> None:
+        if self.sorts_in_forward():
+            return  # (the compositing forward sorts its own tile's bin)
         check(self.lib.gsl_fused_bin(ptr(self.Q0), ptr(self.radii), self.N, self.tw, self.th, self.ty0, self.ty1,
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
                                      ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, int(self.deterministic),
@@ -310,6 +324,7 @@ class RenderContext:
                                          self.long_passes, current_stream()), "gsl_long_sort")
 
     def _raster_fwd(self) -> None:
+        sif = self.sorts_in_forward()
         check(self.lib.gsl_fused_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
                                             self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
@@ -317,9 +332,12 @@ class RenderContext:
                                             ptr(self.ws) if self.bins is not None else None,
                                             ptr(self.hits) if self.record_hits else None,
                                             ptr(self.hit_counts) if self.record_hits else None, self.long_min,
+                                            ptr(self.bins) if sif else None, self.bin_cap if sif else 0,
+                                            ptr(self.n_is) if sif else None, ptr(self.flags) if sif else None,
                                             current_stream()),
               "gsl_fused_raster_fwd")
-        self._counters_dirty = False
+        if not sif:  # (sorting forward: the counters stay set until the backward clears them)
+            self._counters_dirty = False
         self._hits_valid = self.record_hits and self.hits is not None
         if self.long_min:
             check(self.lib.gsl_long_raster_fwd(ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W,
@@ -334,18 +352,22 @@ class RenderContext:
         common = (ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), self.D, int(self.ed), self.W, self.H, self.tw, self.th,
                   self.ty0, self.ty1, ptr(self.offs), ptr(self.flatten_ids), self.capacity, ptr(self.render),
                   ptr(self.alphas), ptr(self.last_ids), ptr(v_render), ptr(v_alphas))
+        clear = self.sorts_in_forward() and self._counters_dirty  # the sorting forward left the tile counters set
         if self.tiny:
             loss = tracking_loss if tracking_loss is not None else (None, 0.0, 0.0, None)
             check(self.lib.gsl_tiny_raster_bwd(*common, ptr(self.trec), ptr(self.vcT), self.row0, self.row1,
                                                ptr(self.flags), self.long_min, ptr(loss[0]), float(loss[1]),
-                                               float(loss[2]), ptr(loss[3]), current_stream()), "gsl_tiny_raster_bwd")
+                                               float(loss[2]), ptr(loss[3]), ptr(self.ws) if clear else None,
+                                               current_stream()), "gsl_tiny_raster_bwd")
             # (pass 2, the fold of the slabs into gradient rows, runs inside the projection backward)
         else:
             check(self.lib.gsl_fused_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
                                                 ptr(self.vrow), ptr(self.hits) if self._hits_valid else None,
                                                 ptr(self.hit_counts) if self._hits_valid else None, self.long_min,
-                                                current_stream()),
+                                                ptr(self.ws) if clear else None, current_stream()),
                   "gsl_fused_raster_bwd")
+        if clear:
+            self._counters_dirty = False
         if self.long_min:  # the segments of the long tiles: rows added to vacc
             check(self.lib.gsl_long_raster_bwd(*common, ptr(self.vacc), self.row0, self.row1, ptr(self.Qh),
                                                ptr(self.hits) if self._hits_valid else None,

@@ -11,6 +11,7 @@
 // ballot so hot tiles see one atomic per wave instead of 64.
 #include <cstdlib>
 #include "gsloc_common.h"
+#include "sort_dev.h"
 
 namespace gsl {
 
@@ -353,71 +354,6 @@ __device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* 
 // needs a barrier or LDS.  Measured against the LDS version it replaces: see DESIGN.md.  Lists longer than 2048
 // entries (a pile of splats in one tile) are sorted by the whole workgroup block-wise, bitonic_sort_long.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-  lo = (unsigned)__shfl_xor((int)lo, mask, 64);
-  hi = (unsigned)__shfl_xor((int)hi, mask, 64);
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {  // a <- min, b <- max
-  bool sw = a > b;
-  uint64_t t = sw ? b : a;
-  b = sw ? a : b;
-  a = t;
-}
-__device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, bool keep_min) {
-  bool lt = o < a;
-  return (lt == keep_min) ? o : a;
-}
-
-template <int LK>
-__device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane) {
-  constexpr int KPT = 1 << LK;
-  // stages whose blocks fit inside one lane's registers
-#pragma unroll
-  for (int lk = 1; lk <= LK; ++lk) {
-#pragma unroll
-    for (int r = 0; r < KPT; ++r) {
-      int p = r ^ ((1 << lk) - 1);
-      if (r < p) cswap(k[r], k[p]);
-    }
-#pragma unroll
-    for (int lj = lk - 2; lj >= 0; --lj)
-#pragma unroll
-      for (int r = 0; r < KPT; ++r) {
-        int p = r ^ (1 << lj);
-        if (r < p) cswap(k[r], k[p]);
-      }
-  }
-  // stages that span 2^tb lanes: the flip pairs (lane, r) with (lane ^ (2^tb - 1), KPT - 1 - r), the half-cleaners
-  // at lane distance 2^b pair equal registers, the rest is register-to-register again
-#pragma unroll 1
-  for (int tb = 1; tb <= 6; ++tb) {
-    int mask = (1 << tb) - 1;
-    bool keep_min = ((lane >> (tb - 1)) & 1) == 0;
-#pragma unroll
-    for (int r = 0; r < KPT / 2; ++r) {
-      uint64_t o_r = shfl_xor_u64(k[KPT - 1 - r], mask);
-      uint64_t o_p = shfl_xor_u64(k[r], mask);
-      k[r] = pick(k[r], o_r, keep_min);
-      k[KPT - 1 - r] = pick(k[KPT - 1 - r], o_p, keep_min);
-    }
-#pragma unroll 1
-    for (int b = tb - 2; b >= 0; --b) {
-      bool km = ((lane >> b) & 1) == 0;
-#pragma unroll
-      for (int r = 0; r < KPT; ++r) k[r] = pick(k[r], shfl_xor_u64(k[r], 1 << b), km);
-    }
-#pragma unroll
-    for (int lj = LK - 1; lj >= 0; --lj)
-#pragma unroll
-      for (int r = 0; r < KPT; ++r) {
-        int p = r ^ (1 << lj);
-        if (r < p) cswap(k[r], k[p]);
-      }
-  }
-}
-
 template <int LK>
 __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int lane,
                                                uint64_t* __restrict__ keys_out, int32_t* __restrict__ flatten_ids,
@@ -626,18 +562,6 @@ __global__ __launch_bounds__(64) void k_long_sort_seg(const int32_t* __restrict_
     if (lane * KPL + r < m) dst[lane * KPL + r] = k[r];
 }
 
-// smallest ia in [lo, hi] such that the first d merged elements take ia from A (keys are unique)
-__device__ __forceinline__ int merge_diag(const uint64_t* __restrict__ A, int lenA, const uint64_t* __restrict__ B, int lenB,
-                                          int d) {
-  int lo = max(0, d - lenB), hi = min(d, lenA);
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (A[mid] <= B[d - 1 - mid]) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
 // merge_diag by the 64 lanes of a wave together (every lane calls it and gets the result): 64 probes per round instead
 // of one, so a diagonal of a 16 k-key run costs 3 dependent global loads instead of 14 (the searches were most of a
 // merge pass: 7 us each, eight passes per frame)
@@ -712,66 +636,6 @@ __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ t
   }
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// One tile per 256-thread workgroup (lists of a few hundred to 2048 keys).  One wave sorting a 1 460-key list in registers
-// is 60 us of pure latency when a strip has fewer tiles than the chip has SIMDs (8 strips of workload X), and a bitonic
-// network over the padded power of two does n log^2 n work.  Here every wave sorts a quarter of the list in registers
-// (wave_sort_regs), the four runs go to LDS and two merge-path passes (every thread merges its 2^LK outputs) finish the
-// job: a third of the compare-exchanges, a quarter of the critical path.  Same result: the keys are unique.
-// ------------------------------------------------------------------------------------------------
-template <int LK>
-__device__ __forceinline__ void wg_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int tid,
-                                             uint64_t* __restrict__ lds, uint64_t* __restrict__ keys_out,
-                                             int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
-                                             int64_t cam_enc) {
-  constexpr int KPT = 1 << LK, RUN = 64 * KPT;
-  const int lane = tid & 63, wv = tid >> 6;
-  uint64_t k[KPT];
-  const int e0 = wv * RUN + lane * KPT;
-#pragma unroll
-  for (int r = 0; r < KPT; ++r) k[r] = (e0 + r < n) ? src[e0 + r] : ~0ull;
-  wave_sort_regs<LK>(k, lane);
-  uint64_t* bufA = lds;
-  uint64_t* bufB = lds + 4 * RUN;
-#pragma unroll
-  for (int r = 0; r < KPT; ++r) bufA[e0 + r] = k[r];
-  __syncthreads();
-  {  // runs (0, 1) and (2, 3) -> two runs of 2 RUN in bufB
-    const int p = tid >> 7, l = tid & 127;
-    const uint64_t* A = bufA + p * 2 * RUN;
-    const uint64_t* B = A + RUN;
-    const int d0 = l * KPT;
-    int ia = merge_diag(A, RUN, B, RUN, d0), ib = d0 - ia;
-#pragma unroll
-    for (int q = 0; q < KPT; ++q) {
-      uint64_t v;
-      if (ib >= RUN || (ia < RUN && A[ia] <= B[ib])) v = A[ia++];
-      else v = B[ib++];
-      bufB[p * 2 * RUN + d0 + q] = v;
-    }
-  }
-  __syncthreads();
-  {  // the two runs of 2 RUN -> the result
-    const uint64_t* A = bufB;
-    const uint64_t* B = bufB + 2 * RUN;
-    const int d0 = tid * KPT;
-    if (d0 < n) {
-      int ia = merge_diag(A, 2 * RUN, B, 2 * RUN, d0), ib = d0 - ia;
-#pragma unroll
-      for (int q = 0; q < KPT; ++q) {
-        uint64_t v;
-        if (ib >= 2 * RUN || (ia < 2 * RUN && A[ia] <= B[ib])) v = A[ia++];
-        else v = B[ib++];
-        if (d0 + q < n) {
-          flatten_ids[s + d0 + q] = (int32_t)(uint32_t)v;
-          if (isect_ids) isect_ids[s + d0 + q] = cam_enc | ((int64_t)t << 32) | (int64_t)(v >> 32);
-          if (keys_out) keys_out[s + d0 + q] = v;
-        }
-      }
-    }
-  }
-}
 
 // Same contract as k_tile_sort (offsets from the counters in binned mode, overflow flags, long lists left to
 // gsl_long_sort), one tile per workgroup.

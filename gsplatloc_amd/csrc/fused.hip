@@ -1012,7 +1012,8 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
                                          const uint32_t* isect_hits, const int32_t* isect_hit_counts, int long_min,
-                                         void* long_ws, int max_seg, int rgb_flag_index, void* stream);
+                                         void* long_ws, int max_seg, int rgb_flag_index, void* clear_ws,
+                                         void* stream);
 
 #define GSL_F_DISPATCH(D, ED, CALL)                     \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }   \
@@ -1028,7 +1029,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
                                    const float* render, const float* alphas, const int32_t* last_ids,
                                    const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
                                    const void* Qh, float* vrow, const uint32_t* isect_hits,
-                                   const int32_t* isect_hit_counts, int long_min, void* stream) {
+                                   const int32_t* isect_hit_counts, int long_min, void* clear_ws, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -1041,6 +1042,7 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   if (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
+  if (vrow && clear_ws) return GSL_ERR_BAD_ARG;  // (the deterministic mode keeps the separate sort launch)
   if (vrow) {  // deterministic mode: one row per intersection, plain stores, no atomics anywhere
 #define CALL_MD(DD, EE)                                                                                       \
   hipLaunchKernelGGL((gsl::k_mraster_bwd<DD, EE, true>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,    \
@@ -1055,7 +1057,8 @@ extern "C" int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const floa
   // non-deterministic path: 16-lane groups, one workgroup per quadrant (raster_g16.hip)
   return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                    capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                   isect_hits, isect_hit_counts, long_min, nullptr, 0, 4 * tile_w * tile_h, stream);
+                                   isect_hits, isect_hit_counts, long_min, nullptr, 0, 4 * tile_w * tile_h, clear_ws,
+                                   stream);
 }
 
 // Compositing backward of the long tile lists (the segments gsl_long_raster_fwd listed in long_ws): adds into vacc.
@@ -1075,7 +1078,7 @@ extern "C" int gsl_long_raster_bwd(const float* Q0, const float* Q1, const float
   if (!flatten_ids || (!Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2)))) return GSL_ERR_BAD_ARG;
   return gsl_g16_raster_bwd_launch(Q0, Q1, Q2, channels, ed, width, height, tile_w, ty0, ty1, tile_offsets, flatten_ids,
                                    capacity, render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh,
-                                   isect_hits, nullptr, long_min, long_ws, max_seg, 0, stream);
+                                   isect_hits, nullptr, long_min, long_ws, max_seg, 0, nullptr, stream);
 }
 
 extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, const float* scales,

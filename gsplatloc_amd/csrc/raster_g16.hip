@@ -389,8 +389,14 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
     const uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts, int long_min, LongWs lw,
-    int32_t* __restrict__ rgb_flag) {
+    int32_t* __restrict__ rgb_flag, int32_t* __restrict__ clear_counts, int32_t* __restrict__ clear_state) {
   __shared__ QStage<D, CG> sb;
+  // (a forward that sorted its own bins could not clear the tile counters, raster_px.hip k_praster_fwd SORT: the first
+  // launch of the backward does, one lane per tile)
+  if (!LONG && (CG == 1 || D == 3) && clear_counts && (blockIdx.x & 3) == 0 && threadIdx.x == 0) {
+    clear_counts[ty0 * tile_w + (blockIdx.x >> 2)] = 0;
+    if (blockIdx.x == 0 && clear_state) *clear_state = 0;
+  }
   // rgb_flag (may be NULL; D = 4 only): raised by the depth-only kernel when it leaves a quadrant to the full-colour
   // kernel, cleared by the compositing forward.  The full-colour launch returns on a clear flag after one load per
   // workgroup instead of reading its 64 pixels' upstream gradient to find out that it has nothing to do (GsplatLoc's
@@ -516,6 +522,8 @@ extern "C" int gsl_g16_stats(unsigned long long* host_out, int reset) {
 }
 #endif
 
+extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles);  // fused.hip: the state word inside ws
+
 // Launch of the G16 backward (called by gsl_fused_raster_bwd in fused.hip for the non-deterministic path).
 extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                          int height, int tile_w, int ty0, int ty1, const int32_t* tile_offsets,
@@ -523,7 +531,8 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
                                          const float* alphas, const int32_t* last_ids, const float* v_render,
                                          const float* v_alphas, float* vacc, int row0, int row1, const void* Qh,
                                          const uint32_t* isect_hits, const int32_t* isect_hit_counts, int long_min,
-                                         void* long_ws, int max_seg, int rgb_flag_index, void* stream) {
+                                         void* long_ws, int max_seg, int rgb_flag_index, void* clear_ws,
+                                         void* stream) {
   // long_ws == NULL: the tiles of the strip (those longer than long_min, if > 0, are skipped);
   // long_ws != NULL: only the (tile, segment) pairs the forward's long-list pass listed there
   hipStream_t st = (hipStream_t)stream;
@@ -532,18 +541,20 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
   const bool lng = long_ws != nullptr;
   // (the flag sits behind the 4 n_tiles hit-list lengths; the long-list launches, which have no lengths array, go without)
   int32_t* rgb_flag = isect_hit_counts ? const_cast<int32_t*>(isect_hit_counts) + rgb_flag_index : nullptr;
+  int32_t* clear_counts = (int32_t*)clear_ws;
+  int32_t* clear_state = clear_ws ? gsl_fused_bin_state(clear_ws, rgb_flag_index / 4) : nullptr;  // (4 n_tiles)
 #define CALL_Q(DD, EE, CC)                                                                                   \
   do {                                                                                                       \
     if (lng)                                                                                                 \
       hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, true>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag, clear_counts, clear_state);                            \
     else                                                                                                     \
       hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, false>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag, clear_counts, clear_state);                            \
   } while (0)
   if (channels == 1) { if (ed) CALL_Q(1, true, 1); else CALL_Q(1, false, 1); }
   else if (channels == 3) { CALL_Q(3, false, 3); }

@@ -23,6 +23,7 @@
 // per-pixel sequence of composited splats -- and therefore every output -- is unchanged.
 #include "gsloc_common.h"
 #include "loss_dev.h"
+#include "sort_dev.h"
 
 namespace gsl {
 
@@ -279,17 +280,82 @@ __device__ __forceinline__ TilePixel tile_pixel(int tile, int tile_w, int tid) {
   return t;
 }
 
+// SORT = 2 / 3 (binned projection, whole frame, every list <= 1024 / 2048 keys, no long lists): the kernel turns its
+// tile's bin into the sorted list ITSELF before compositing it -- what k_tile_sort_wg does in a launch of its own: adds up
+// the sizes of the tiles before its own (offsets, total, overflow flags), sorts (four waves sort quarters in registers,
+// two merge-path passes in LDS, sort_dev.h) and writes tile_offsets / flatten_ids for the backward.  The tracker's
+// iteration loses a launch (10 of 85 us at 102 k Gaussians).  The tile counters cannot be cleared here any more -- other
+// workgroups are still adding them up -- so the compositing BACKWARD clears them (clear_counts of k_tiny_bwd /
+// k_qraster_bwd); a forward nobody back-propagates leaves them to the host (RenderContext zeroes them).
+struct FwdSort {
+  uint64_t* bins;
+  const int32_t* counts;
+  int32_t* tile_offsets;  // out
+  int32_t* flatten_ids;   // out
+  int32_t* n_isects;      // out (total)
+  int32_t* flags;         // flags[1], flags[2]: a tile outgrew its bin
+  int bin_cap;
+};
+template <int SORT> struct FwdListPtr { typedef const int32_t* __restrict__ type; };
+template <> struct FwdListPtr<2> { typedef const int32_t* type; };  // (the kernel writes what these point to)
+template <> struct FwdListPtr<3> { typedef const int32_t* type; };
+
 // long_min > 0: tiles whose list is longer than long_min entries are left to the long-list kernels below.
-template <int D, bool ED>
+template <int D, bool ED, int SORT>
 __global__ __launch_bounds__(256) void k_praster_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    int tile_w, int ty0, typename FwdListPtr<SORT>::type tile_offsets, typename FwdListPtr<SORT>::type flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
     int row0, int row1, const uint4* __restrict__ Qh, int32_t* __restrict__ clear_counts,
     int32_t* __restrict__ clear_state, uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts,
-    int long_min, int n_tiles_total) {
-  __shared__ PStage<D> sb;
+    int long_min, int n_tiles_total, FwdSort fs) {
+  constexpr size_t SORT_BYTES = SORT ? (size_t)8 * 64 * (1 << SORT) * sizeof(uint64_t) : 0;  // two buffers of 4 runs
+  constexpr size_t LDS_BYTES = sizeof(PStage<D>) > SORT_BYTES ? sizeof(PStage<D>) : SORT_BYTES;
+  __shared__ __align__(16) unsigned char smem[LDS_BYTES];  // the sort's merge buffers, then the compositing stage
+  PStage<D>& sb = *reinterpret_cast<PStage<D>*>(smem);
+  __shared__ int s_scan[5];
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  long long sorted_rs = 0, sorted_re = 0;
+  if constexpr (SORT != 0) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int acc = 0;
+    for (int i = tid; i < tile; i += 256) acc += min(fs.counts[i], fs.bin_cap);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) s_scan[wv] = acc;
+    if (tid == 0) {
+      int c_own = fs.counts[tile];
+      s_scan[4] = min(c_own, fs.bin_cap);
+      if (c_own > fs.bin_cap && fs.flags) { fs.flags[1] = 1; atomicMax(&fs.flags[2], c_own); }
+    }
+    __syncthreads();
+    long long s0 = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3], e0 = s0 + s_scan[4];
+    if (tid == 0) {
+      fs.tile_offsets[tile] = (int32_t)s0;
+      if (tile == n_tiles_total - 1) {
+        fs.tile_offsets[tile + 1] = (int32_t)e0;
+        if (fs.n_isects) fs.n_isects[0] = (int32_t)e0;
+      }
+    }
+    if (e0 > capacity) e0 = capacity;  // (the total tells the host; what fits is sorted and composited)
+    int n = (int)max(e0 - s0, (long long)0);
+    if (n > 256) {
+      wg_sort_tile<SORT>(fs.bins + (size_t)tile * (size_t)fs.bin_cap, n, s0, tile, tid, reinterpret_cast<uint64_t*>(smem),
+                         nullptr, fs.flatten_ids, nullptr, 0);
+    } else if (n > 0 && wv == 0) {  // a short list: one wave's registers, no merge passes
+      const uint64_t* src = fs.bins + (size_t)tile * (size_t)fs.bin_cap;
+      uint64_t k[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) k[r] = (lane * 4 + r < n) ? src[lane * 4 + r] : ~0ull;
+      wave_sort_regs<2>(k, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lane * 4 + r < n) fs.flatten_ids[s0 + lane * 4 + r] = (int32_t)(uint32_t)k[r];
+    }
+    __syncthreads();  // the list is in flatten_ids (this workgroup's own stores: visible after the barrier's fence)
+    sorted_rs = s0;
+    sorted_re = s0 + n;
+  }
   // binned projection: the tile-size counter of this tile has been consumed by the sort kernel; clear it for the next
   // projection (no clearing launch; sizes of tiles outside the strip are never raised)
   if (clear_counts && threadIdx.x == 0) {
@@ -305,10 +371,17 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
   bool inside = (i < H) && (j < W) && (i >= row0) && (i < row1);
   bool done = !inside;
 
-  long long rs = tile_offsets[tile], re = tile_offsets[tile + 1];
-  if (re > capacity) re = capacity;
-  if (rs > re) rs = re;
-  if (long_min > 0 && re - rs > long_min) return;
+  long long rs, re;
+  if constexpr (SORT != 0) {
+    rs = sorted_rs;
+    re = sorted_re;
+  } else {
+    rs = tile_offsets[tile];
+    re = tile_offsets[tile + 1];
+    if (re > capacity) re = capacity;
+    if (rs > re) rs = re;
+    if (long_min > 0 && re - rs > long_min) return;
+  }
 
   float T = 1.f;
   int cur_idx = 0;
@@ -533,13 +606,18 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
     long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
     const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
     float2* __restrict__ trec, float* __restrict__ vcT, int row0, int row1, int32_t* __restrict__ flags, int long_min,
-    TinyLoss tl) {
+    TinyLoss tl, int32_t* __restrict__ clear_counts, int32_t* __restrict__ clear_state) {
   constexpr bool RGB = D >= 3;
   constexpr bool DEPTH = (D == 1) || (D == 4);
   __shared__ TStage<D> sb;
   __shared__ int s_final[4];
   __shared__ TinyLossLds<LOSS> sl;
   int tile = ty0 * tile_w + GSL_TILE_OF_BLOCK();
+  // (the forward sorted its own bins and could not clear the tile counters: see k_praster_fwd, SORT)
+  if (clear_counts && threadIdx.x == 0) {
+    clear_counts[tile] = 0;
+    if (blockIdx.x == 0 && clear_state) *clear_state = 0;
+  }
   int tyi = tile / tile_w, txi = tile - tyi * tile_w;
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   int qx = txi * 16 + (wv & 1) * 8, qy = tyi * 16 + (wv >> 1) * 8;
@@ -661,7 +739,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
           const bool ok0 = act && t0 >= t_lane && sg0 >= 0.f && al0 >= GSL_ALPHA_MIN;
           const bool ok1 = two && t1 >= t_lane && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN;
           float cd0 = 0.f, cd1 = 0.f;
-          if (RGB) {
+          if constexpr (RGB) {
             float4 q20 = sb.s2[t0], q21 = sb.s2[t1];
             cd0 = q20.x * vc[0] + q20.y * vc[1] + q20.z * vc[2];
             cd1 = q21.x * vc[0] + q21.y * vc[1] + q21.z * vc[2];
@@ -704,13 +782,15 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
 
 }  // namespace gsl
 
+extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles);  // fused.hip: the state word inside ws
+
 extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                    int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                    const int32_t* flatten_ids, int64_t capacity, const float* render,
                                    const float* alphas, const int32_t* last_ids, const float* v_render,
                                    const float* v_alphas, float* trec, float* vcT, int row0, int row1,
                                    int32_t* flags, int long_min, const float* loss_depth_gt, float depth_lambda,
-                                   float edge_lambda, float* loss_partials, void* stream) {
+                                   float edge_lambda, float* loss_partials, void* clear_ws, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -734,7 +814,8 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
   hipLaunchKernelGGL((gsl::k_tiny_bwd<DD, EE, LL>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,        \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,         \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas,         \
-                     (float2*)trec, vcT, row0, row1, flags, long_min, tl)
+                     (float2*)trec, vcT, row0, row1, flags, long_min, tl, (int32_t*)clear_ws,                \
+                     clear_ws ? gsl_fused_bin_state(clear_ws, tile_w * tile_h) : (int32_t*)nullptr)
 #define CALL_TL(DD, EE) do { if (loss) CALL_TB(DD, EE, true); else CALL_TB(DD, EE, false); } while (0)
   if (channels == 1) { if (ed) CALL_TL(1, true); else CALL_TL(1, false); }
   else if (channels == 3) { CALL_TB(3, false, false); }
@@ -746,7 +827,6 @@ extern "C" int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float
   return GSL_OK;
 }
 
-extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles);  // fused.hip: the state word inside ws
 
 #define GSL_P_DISPATCH(D, ED, CALL)                                \
   if (D == 1) { if (ED) CALL(1, true); else CALL(1, false); }      \
@@ -755,11 +835,15 @@ extern "C" int32_t* gsl_fused_bin_state(void* ws, int n_tiles);  // fused.hip: t
   else return GSL_ERR_BAD_ARG;
 
 // Compositing forward (k_praster_fwd).  Pixel rows outside [row0, row1) are not touched.
+// sort_bins != NULL (binned projection, whole frame, bin_cap <= 2048, long_min == 0): the kernel also does gsl_fused_bin's
+// work for its tile -- gsl_fused_bin is then NOT called; tile_offsets, flatten_ids and n_isects are outputs, flags as in
+// gsl_fused_bin, and the tile counters in binned_ws stay set until a compositing backward given clear_ws clears them.
 extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                                  int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
                                  int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws,
-                                 uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min, void* stream) {
+                                 uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min, void* sort_bins,
+                                 int bin_cap, int32_t* n_isects, int32_t* flags, void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -770,17 +854,31 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (isect_hits && !isect_hit_counts) return GSL_ERR_BAD_ARG;
   if (isect_hits && capacity >= ((int64_t)1 << 28)) return GSL_ERR_BAD_ARG;  // a hit entry keeps the list index in 28 bits
+  const bool sort = sort_bins != nullptr;
+  if (sort && (!binned_ws || !n_isects || bin_cap <= 0 || bin_cap > 2048 || long_min != 0 || ty0 != 0 || ty1 != tile_h ||
+               !flatten_ids))
+    return GSL_ERR_BAD_ARG;
   if (ty0 == ty1) return GSL_OK;
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
-#define CALL_PF(DD, EE)                                                                                       \
-  hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,          \
+  gsl::FwdSort fs{(uint64_t*)sort_bins, (const int32_t*)binned_ws, const_cast<int32_t*>(tile_offsets),
+                  const_cast<int32_t*>(flatten_ids), n_isects, flags, bin_cap};
+  // (sorting variant: the counters are still being added up by other workgroups -- the backward clears them)
+  int32_t* clear_counts = sort ? nullptr : (int32_t*)binned_ws;
+  int32_t* clear_state = sort ? nullptr : gsl_fused_bin_state(binned_ws, tile_w * tile_h);
+  const int lk = !sort ? 0 : (bin_cap <= 1024 ? 2 : 3);
+#define CALL_PF3(DD, EE, SS)                                                                                  \
+  hipLaunchKernelGGL((gsl::k_praster_fwd<DD, EE, SS>), dim3(nblk), dim3(256), 0, st, (const float4*)Q0,      \
                      (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,          \
                      flatten_ids, (long long)capacity, render, alphas, last_ids, row0, row1, (const uint4*)Qh,     \
-                     (int32_t*)binned_ws, gsl_fused_bin_state(binned_ws, tile_w * tile_h), isect_hits,          \
-                     isect_hit_counts, long_min, tile_w * tile_h)
+                     clear_counts, clear_state, isect_hits, isect_hit_counts, long_min, tile_w * tile_h, fs)
+#define CALL_PF(DD, EE)                                                                          \
+  do {                                                                                           \
+    if (lk == 0) CALL_PF3(DD, EE, 0); else if (lk == 2) CALL_PF3(DD, EE, 2); else CALL_PF3(DD, EE, 3); \
+  } while (0)
   GSL_P_DISPATCH(channels, ed, CALL_PF)
 #undef CALL_PF
+#undef CALL_PF3
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

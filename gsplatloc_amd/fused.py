@@ -80,7 +80,8 @@ class _FusedRasterization(torch.autograd.Function):
         hit_counts = torch.empty(4 * n_tiles + 1, dtype=i32, device=dev)
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
-                                       ptr(last_ids), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, st),
+                                       ptr(last_ids), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, None, 0, None, None,
+                                       st),
               "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
@@ -117,7 +118,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_raster_bwd(ptr(Q0), ptr(Q1), ptr(Q2) if rgb else None, D, int(ed), W, H, tw, th, ty0,
                                        ty1, ptr(offs), ptr(flatten_ids) if n_isects else None, n_isects,
                                        ptr(render), ptr(alphas), ptr(last_ids), ptr(v_render), ptr(v_alphas),
-                                       ptr(vacc), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, st),
+                                       ptr(vacc), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, None, st),
               "gsl_fused_raster_bwd")
         ni = ctx.needs_input_grad
         full = any(ni[:5])

@@ -58,7 +58,8 @@ class GraphTracker:
         self.K_sh = (sh_deg + 1) ** 2
         self.rc = RenderContext(self.N, self.W, self.H, render_mode, sh_degree=sh_deg, K_sh=self.K_sh, device=self.dev,
                                 near_plane=config.gs.near_plane, far_plane=config.gs.far_plane,
-                                tile_rows=self.render_rows, pixel_rows=self.pixel_rows, full_grads=False)
+                                tile_rows=self.render_rows, pixel_rows=self.pixel_rows, full_grads=False,
+                                sort_in_forward=group is None)  # (every forward of an iteration has its backward)
         f32 = torch.float32
         d = self.dev
         self.means = torch.zeros(self.N, 3, dtype=f32, device=d)

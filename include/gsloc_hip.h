@@ -227,14 +227,21 @@ int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int 
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
                          void* binned_ws, uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min,
-                         void* stream);
+                         void* sort_bins, int bin_cap, int32_t* n_isects, int32_t* flags, void* stream);
+/* sort_bins != NULL (binned projection, whole frame, bin_cap <= 2048, long_min == 0): every workgroup first does
+ * gsl_fused_bin's work for its own tile -- adds up the sizes of the tiles before it, sorts its bin in LDS, writes
+ * tile_offsets / flatten_ids (outputs then, despite the const) / n_isects and raises flags like gsl_fused_bin -- and
+ * gsl_fused_bin is NOT called: the tracker's iteration goes without the sort launch.  The tile counters in binned_ws then
+ * stay set until a compositing backward that is given clear_ws (gsl_fused_raster_bwd / gsl_tiny_raster_bwd) clears
+ * them; after a forward nobody back-propagates the caller zeroes binned_ws before the next gsl_fused_project. */
 int gsl_fused_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          const float* render, const float* alphas, const int32_t* last_ids,
                          const float* v_render, const float* v_alphas, float* vacc, int row0, int row1,
                          const void* Qh, float* vrow, const uint32_t* isect_hits,
-                         const int32_t* isect_hit_counts, int long_min, void* stream);
+                         const int32_t* isect_hit_counts, int long_min, void* clear_ws, void* stream);
+/* clear_ws (may be NULL): the binned_ws whose tile counters this backward clears (see gsl_fused_raster_fwd, sort_bins). */
 /* Long tile lists split over workgroups (long_min > 0 in the calls above and in gsl_tiny_raster_bwd: tiles whose list
  * is longer than long_min entries are skipped there and handled here).  A pile of splats in one tile -- the invalid
  * pixels of a TUM depth frame, /root/reference/src/data/Image.py:29-35 -- is cut into segments of gsl_long_segment() entries, one
@@ -293,7 +300,7 @@ int gsl_tiny_raster_bwd(const float* Q0, const float* Q1, const float* Q2, int c
                         const float* render, const float* alphas, const int32_t* last_ids,
                         const float* v_render, const float* v_alphas, float* trec, float* vcT,
                         int row0, int row1, int32_t* flags, int long_min, const float* loss_depth_gt,
-                        float depth_lambda, float edge_lambda, float* loss_partials, void* stream);
+                        float depth_lambda, float edge_lambda, float* loss_partials, void* clear_ws, void* stream);
 /* loss_depth_gt != NULL (whole frame, channels 1 or 4): the kernel computes the tracking loss of gsl_tracking_loss for
  * its tile itself -- the tile is that kernel's 16x16 block -- WRITES v_render's depth channel and
  * loss_partials[tiles][2], and back-propagates from that gradient (v_render's other channels count as zero): the

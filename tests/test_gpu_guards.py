@@ -181,3 +181,36 @@ def test_long_list_results_do_not_depend_on_stale_lds():
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert torch.isfinite(out[0][2]).all()
     assert float((out[0][2] - out[1][2]).abs().max()) <= 1e-4 * float(out[1][2].abs().max())
+
+
+@pytest.mark.parametrize("sigma_px,mode", [(0.0, "RGB+ED"), (1.0, "RGB+ED"), (1.0, "ED")])
+def test_no_write_outside_buffers_when_the_forward_sorts(sigma_px, mode, monkeypatch):
+    """The canaries around a context whose compositing forward sorts its own tile bins (sort_in_forward: the tracker's
+    set-up) -- tile_offsets, flatten_ids, n_isects and the flags are then outputs of that kernel."""
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import perturbed_pose, random_scene
+
+    dev = torch.device("cuda")
+    if sigma_px == 0.0:
+        monkeypatch.setenv("GSLOC_BWD", "tiny")
+    N, W, H = 50_001, 333, 217
+    sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev)
+    viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    ctx = RenderContext(N, W, H, mode, sh_degree=1, K_sh=4, device=dev, full_grads=True, sort_in_forward=True)
+    inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, sc["K"].contiguous())
+    ctx.calibrate(*inp, headroom=1.05)
+    assert ctx.sorts_in_forward()
+    homes = _rehome(ctx)
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(H, W, ctx.D, generator=g).to(dev)
+    va = torch.randn(H, W, 1, generator=g).to(dev)
+    for _ in range(3):
+        ctx.forward(*inp)
+        ctx.backward(v, va, full=True)
+    ctx.forward(*inp)  # (and one nobody back-propagates)
+    ctx.forward(*inp)
+    ctx.backward(v, va, full=True)
+    torch.cuda.synchronize()
+    ctx.check_capacity()
+    _check(homes)
+    assert torch.isfinite(ctx.v_viewmat).all()

@@ -869,3 +869,61 @@ def test_cached_drop_in_call_recomputes_recalibrates_and_owns_its_outputs():
     assert torch.equal(rg.detach(), ref["big"][0])
     assert rel_inf(Vgg.grad, ref["big"][1]) < 1e-5 and rel_inf(mg.grad, ref["big"][2]) < 1e-5
     clear_context_cache()
+
+
+@pytest.mark.parametrize("sigma_px,N,bwd", [(0.0, 60000, "tiny"), (1.3, 30000, "auto"), (2.2, 40000, "auto")])
+def test_forward_that_sorts_its_own_bins_matches_the_separate_sort_launch(sigma_px, N, bwd, monkeypatch):
+    """RenderContext(sort_in_forward=True): gsl_fused_raster_fwd(..., sort_bins) does gsl_fused_bin's work per tile (no
+    sort launch) and the compositing backward clears the tile counters.  Offsets, lists, image bit for bit those of the
+    separate launch; gradients equal; a forward nobody back-propagates is followed by a correct one (the context zeroes
+    the counters); an outgrown bin is flagged.  Bins of <= 1024 keys (LK 2) and of 1025..2048 keys (LK 3); tiny and
+    general backward."""
+    _gpu()
+    from gsplatloc_amd.context import RenderContext
+    monkeypatch.setenv("GSLOC_BWD", bwd)
+    W, H = 260, 200
+    sc = _scene32(N, W, H, sigma_px=sigma_px, opacity=(0.3, 1.0))
+    sh = sh_from_rgb(sc["rgbs"]).to(DEV)
+    ins = [sc[k].to(DEV) for k in ("means", "quats", "scales", "opacities")] + [sh]
+    V0 = torch.linalg.inv(small_pose(0.5, 0.01, dtype=torch.float32)).to(DEV).contiguous()
+    V1 = torch.linalg.inv(small_pose(0.8, 0.02, dtype=torch.float32)).to(DEV).contiguous()
+    K = sc["K"].to(DEV).contiguous()
+    v = torch.randn(H, W, 4, generator=torch.Generator().manual_seed(2)).to(DEV)
+    va = torch.zeros(H, W, 1, device=DEV)
+    got = {}
+    for sif in (False, True):
+        rc = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, sort_in_forward=sif)
+        rc.calibrate(*ins, V0, K)
+        assert rc.sorts_in_forward() == sif and rc.tiny == (bwd == "tiny")
+        if sigma_px > 2.0:
+            assert rc.bin_cap > 1024
+        elif sigma_px > 0:
+            assert rc.bin_cap <= 1024
+        out = []
+        for V in (V0, V1, V1):
+            rc.forward(*ins, V, K)
+            g = rc.backward(v, va)
+            torch.cuda.synchronize()
+            n = rc.check_capacity()
+            out.append(dict(n=n, offs=rc.offs.clone(), ids=rc.flatten_ids[:n].clone(), render=rc.render.clone(),
+                            vm=g["viewmat"].clone(), means=g["means"].clone()))
+        # forward, forward (nobody back-propagated the first), backward
+        rc.forward(*ins, V0, K)
+        rc.forward(*ins, V1, K)
+        g = rc.backward(v, va)
+        torch.cuda.synchronize()
+        n = rc.check_capacity()
+        out.append(dict(n=n, offs=rc.offs.clone(), ids=rc.flatten_ids[:n].clone(), render=rc.render.clone(),
+                        vm=g["viewmat"].clone(), means=g["means"].clone()))
+        got[sif] = out
+        if sif:  # an outgrown bin is flagged by the sorting forward too
+            longest = int((rc.offs[1:] - rc.offs[:-1]).max())
+            rc._alloc_bins(longest // 2)
+            rc.forward(*ins, V1, K)
+            assert rc.bins_overflowed() == longest
+    for a, b in zip(got[False], got[True]):
+        assert a["n"] == b["n"] > 0 and torch.equal(a["offs"], b["offs"]) and torch.equal(a["ids"], b["ids"])
+        assert torch.equal(a["render"], b["render"])
+        assert float((a["vm"] - b["vm"]).abs().max()) <= 1e-5 * float(a["vm"].abs().max())
+        assert float((a["means"] - b["means"]).abs().max()) <= 1e-4 * float(a["means"].abs().max())
+    assert torch.equal(got[True][1]["render"], got[True][3]["render"])

@@ -118,10 +118,13 @@ def test_graph_tracker_iteration_marshals_every_call(monkeypatch):
     assert calls[:n_setup] == ["gsl_pose_init", "gsl_fused_project"]
     # nothing was projected (the launch was refused), so every r_cull is 0 and calibration picked the tiny backward
     assert gt.rc.tiny
-    # one rank, no normal term, tiny backward: the compositing backward computes the loss itself (no gsl_tracking_loss)
-    assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_bin", "gsl_fused_raster_fwd",
-                               "gsl_tiny_raster_bwd", "gsl_fused_project_bwd", "gsl_pose_step"]
+    # one rank, no normal term, tiny backward: the compositing forward sorts its own tile's bin (no gsl_fused_bin) and
+    # the compositing backward computes the loss itself (no gsl_tracking_loss): five launches
+    assert gt.rc.sorts_in_forward()
+    assert calls[n_setup:] == ["gsl_fused_project", "gsl_fused_raster_fwd", "gsl_tiny_raster_bwd",
+                               "gsl_fused_project_bwd", "gsl_pose_step"]
     monkeypatch.setenv("GSLOC_FUSE_LOSS", "0")
+    monkeypatch.setenv("GSLOC_SORT_IN_FORWARD", "0")
     del calls[:]
     gt._iteration()
     assert calls == ["gsl_fused_project", "gsl_fused_bin", "gsl_fused_raster_fwd", "gsl_tracking_loss",
