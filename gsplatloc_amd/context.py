@@ -242,11 +242,14 @@ class RenderContext:
 
     def sorts_in_forward(self) -> bool:
         """The compositing forward does gsl_fused_bin's work for its own tile (gsl_fused_raster_fwd(..., sort_bins)):
-        asked for (sort_in_forward), binned projection, whole frame, every bin at most 2048 keys, no long lists, not the
+        asked for (sort_in_forward), binned projection, whole frame, every bin at most 1024 keys, no long lists, not the
         deterministic mode.  The tile counters are then cleared by the compositing backward."""
-        return bool(self.sort_in_forward and self.bins is not None and 0 < self.bin_cap <= 2048 and self.long_min == 0
-                    and not self.deterministic and self.ty0 == 0 and self.ty1 == self.th
-                    and os.environ.get("GSLOC_SORT_IN_FORWARD", "1") != "0")
+        mode = os.environ.get("GSLOC_SORT_IN_FORWARD", "1")  # "0": never; "force": also for bins of 1025..2048 keys
+        # (bins above 1024 keys need 32 KB of merge buffers per workgroup: the forward then loses more occupancy than the
+        # launch saves -- 1 M random splats, lists of ~740: 0.569 -> 0.597 ms per step -- so those keep the sort launch)
+        return bool(self.sort_in_forward and mode != "0" and self.bins is not None
+                    and 0 < self.bin_cap <= (2048 if mode == "force" else 1024) and self.long_min == 0
+                    and not self.deterministic and self.ty0 == 0 and self.ty1 == self.th)
 
     def _screen_coherent_order(self) -> bool:
         """Do consecutive Gaussians land in the same or a neighbouring tile (a back-projected depth frame in pixel

@@ -881,6 +881,7 @@ def test_forward_that_sorts_its_own_bins_matches_the_separate_sort_launch(sigma_
     _gpu()
     from gsplatloc_amd.context import RenderContext
     monkeypatch.setenv("GSLOC_BWD", bwd)
+    monkeypatch.setenv("GSLOC_SORT_IN_FORWARD", "force")  # (RenderContext itself stops at bins of 1024 keys)
     W, H = 260, 200
     sc = _scene32(N, W, H, sigma_px=sigma_px, opacity=(0.3, 1.0))
     sh = sh_from_rgb(sc["rgbs"]).to(DEV)
