@@ -1,13 +1,14 @@
 #!/usr/bin/env bash
-# Dev: run scripts/gpu_quick.sh (parity subset + stage times at R, D, pile) with build_ab/lib_<name>.so in place of the
-# built library.  usage: gpu_lib_ab.sh <name> [...]   ("default" = the library as built)
+# Dev: stage times at R / D with build_ab/lib_<name>.so in place of the built library ("default" = as built).
+# usage: gpu_lib_ab.sh <name> [...]
 set -o pipefail
 cp gsplatloc_amd/libgsloc_hip.so build_ab/lib_default.so
-rc=0
 for v in "$@"; do
-  echo "== $v"
   cp build_ab/lib_$v.so gsplatloc_amd/libgsloc_hip.so
-  bash scripts/gpu_quick.sh || { rc=1; break; }
+  for wl in R D; do
+    timeout -k 10 300 python3 bench.py --workload $wl --no-cpu-baseline --no-tracker --no-variants --steps 40 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.readlines()[-1]); print('$v $wl', round(d['ms_per_step'], 4), {k: round(v, 4) for k, v in d['roofline']['stage_ms'].items()})"
+  done
 done
 cp build_ab/lib_default.so gsplatloc_amd/libgsloc_hip.so
-exit $rc
