@@ -331,6 +331,70 @@ def test_long_tile_list_is_split_over_workgroups_and_matches_the_oracle():
     assert errs["v_viewmat"] < 8e-4
 
 
+def test_several_long_lists_of_different_lengths_match_the_single_workgroup_path():
+    """Three piles of different sizes in three tiles (2 600, 5 001 and 9 777 extra points at three spots in front of the
+    camera -- lengths that are no multiple of the 128-entry compositing segment or of the 512-key sort run) on top of
+    a depth frame: the map of (tile, segment) pairs, the multi-workgroup sort and the segment compositing with several
+    long tiles at once.  Lists bit for bit those of the single-workgroup path (GSLOC_LONG_LISTS=0), image and gradients
+    to the association of the float32 transmittance product."""
+    import os
+
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.synthetic import depth_frame_scene
+
+    dev = torch.device("cuda")
+    W, H = 640, 480
+    sc = depth_frame_scene(W, H, stride=2, holes=False, device=dev)
+    K = sc["K"]
+    fx, fy, cx, cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+    g = torch.Generator().manual_seed(4)
+    c2w = torch.linalg.inv(sc["viewmat"].cpu().double())
+    extra = []
+    for n, (u, v_, z) in ((2600, (100.3, 90.2, 1.7)), (5001, (333.1, 250.9, 2.4)), (9777, (555.5, 401.7, 0.9))):
+        du = torch.rand(n, generator=g, dtype=torch.float64) * 2.0 - 1.0
+        dv = torch.rand(n, generator=g, dtype=torch.float64) * 2.0 - 1.0
+        zz = z + 0.3 * torch.rand(n, generator=g, dtype=torch.float64)
+        cam = torch.stack([(u + du - cx) / fx * zz, (v_ + dv - cy) / fy * zz, zz], -1)
+        extra.append((cam @ c2w[:3, :3].T + c2w[:3, 3]).float())
+    extra = torch.cat(extra).to(dev)
+    n_extra = extra.shape[0]
+    means = torch.cat([sc["means"], extra]).contiguous()
+    N = means.shape[0]
+    quats = torch.tensor([1.0, 0, 0, 0], device=dev).repeat(N, 1).contiguous()
+    scales = torch.cat([sc["scales"], torch.full((n_extra, 3), 2e-3, device=dev)]).contiguous()
+    opac = torch.cat([sc["opacities"], torch.full((n_extra,), 0.02, device=dev)]).contiguous()  # (low: long walks)
+    sh = torch.cat([sc["sh"], torch.zeros(n_extra, 4, 3, device=dev)]).contiguous()
+    sh[-n_extra:, 0] = torch.rand(n_extra, 3, generator=g).to(dev)
+    inp = (means, quats, scales, opac, sh, sc["viewmat"], K.contiguous())
+    v = _depth_upstream(H, W, seed=9).float().to(dev).contiguous()
+    va = torch.zeros(H, W, 1, device=dev)
+    out = {}
+    for mode in ("1", "0"):
+        os.environ["GSLOC_LONG_LISTS"] = mode
+        try:
+            ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+            ctx.calibrate(*inp)
+        finally:
+            os.environ.pop("GSLOC_LONG_LISTS", None)
+        sizes = ctx.offs[1:] - ctx.offs[:-1]
+        assert (ctx.long_min > 0) == (mode == "1")
+        if mode == "1":
+            assert int((sizes > ctx.long_min).sum()) >= 3, sizes.sort(descending=True).values[:6]
+        for _ in range(2):
+            render, alphas = ctx.forward(*inp)
+            gr = ctx.backward(v, va, full=True)
+        torch.cuda.synchronize()
+        ctx.check_capacity()
+        n = int(ctx.n_is.item())
+        out[mode] = (render.clone(), alphas.clone(), gr["viewmat"].clone(), gr["means"].clone(),
+                     ctx.flatten_ids[:n].clone(), ctx.offs.clone())
+    (r1, a1, gv1, gm1, ids1, offs1), (r0, a0, gv0, gm0, ids0, offs0) = out["1"], out["0"]
+    assert torch.equal(offs1, offs0) and torch.equal(ids1, ids0)
+    assert float((r1 - r0).abs().max()) < 1e-4 and float((a1 - a0).abs().max()) < 1e-5
+    assert rel_inf(gv1[:3], gv0[:3]) < 2e-4, rel_inf(gv1[:3], gv0[:3])
+    assert float((gm1 - gm0).norm() / gm0.norm()) < 2e-4
+
+
 def test_long_list_workspace_overflow_is_flagged_not_overrun():
     """A frame that needs more (tile, segment) pairs than the long-list workspace holds (a pile that jumps onto a tile
     corner appears in up to four lists at once): tiles whose segments do not fit are left out as a whole and the need is
