@@ -245,8 +245,8 @@ def test_graph_tracker_early_stop():
     assert abs(res.steps - ref.steps) <= 2, (res.steps, ref.steps)  # fp32 ties in "loss < best" may shift the stop by an iteration
 
 
-@pytest.mark.parametrize("odd_size", [False, True])
-def test_loss_computed_inside_the_tiny_backward_matches_the_separate_loss_launch(odd_size, monkeypatch):
+@pytest.mark.parametrize("odd_size,mode", [(False, "RGB+ED"), (True, "RGB+ED"), (False, "ED")])
+def test_loss_computed_inside_the_tiny_backward_matches_the_separate_loss_launch(odd_size, mode, monkeypatch):
     """One rank, no normal term, tiny-splat backward: gsl_tiny_raster_bwd(..., loss_depth_gt, ...) computes the tracking
     loss of its tile and back-propagates from it -- same upstream gradient, same loss partials, same pose gradient rows
     and the same trajectory as gsl_tracking_loss followed by the plain backward (GSLOC_FUSE_LOSS=0).  odd_size: an image
@@ -260,14 +260,14 @@ def test_loss_computed_inside_the_tiny_backward_matches_the_separate_loss_launch
     out = {}
     for fuse in ("0", "1"):
         monkeypatch.setenv("GSLOC_FUSE_LOSS", fuse)
-        gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10, use_graph=False)
+        gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10, use_graph=False, render_mode=mode)
         gt.load_frame(*frame)
-        assert gt.rc.tiny and gt.rc.can_fuse_tracking_loss()
+        assert gt.rc.tiny and gt.rc.can_fuse_tracking_loss() and gt.rc.D == (4 if mode == "RGB+ED" else 1)
         gt._render_and_loss()  # one iteration's forward, loss, backward at the initial pose
         torch.cuda.synchronize()
         rows_ptr, n_rows = gt.rc.viewmat_rows()
         one = dict(v=gt.v_render.clone(), partials=gt.partials.clone(), vcT=gt.rc.vcT.clone())
-        gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10)
+        gt = GraphTracker(pts0.shape[0], W, H, cfg, device=DEV, poll=10, render_mode=mode)
         gt.load_frame(*frame)
         res = gt.run()
         out[fuse] = dict(one=one, losses=torch.tensor(res.losses, dtype=torch.float64), c2w=res.final_c2w.clone())
