@@ -38,12 +38,13 @@ _SIGNATURES = {
     "gsl_fused_ws_bytes": (c_size_t, [c_int, c_int]),
     "gsl_fused_project": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_float, c_float,
                                   c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t,
-                                  P, P, c_int, P, P]),
+                                  P, P, c_int, P, P, P]),
     "gsl_fused_bin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int64, P, P, P, P, c_size_t, c_int,
-                              P, c_int, P, P, c_int, P]),
-    "gsl_long_sort": (c_int, [P, c_int, c_int, c_int, c_int, c_int64, P, c_int, P, P, c_int, P, c_size_t, c_int, c_int, P]),
+                              P, c_int, P, P, c_int, P, P, P]),
+    "gsl_long_sort": (c_int, [P, c_int, c_int, c_int, c_int, c_int64, P, c_int, P, P, c_int, P, c_size_t, c_int, c_int, P,
+                              P]),
     "gsl_fused_raster_fwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
-                                     P, P, P, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, P]),
+                                     P, P, P, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, P, P]),
     "gsl_fused_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                      P, P, P, P, P, P, c_int, c_int, P, P, P, P, c_int, P, P]),
     "gsl_long_ws_bytes": (c_size_t, [c_int]),
@@ -71,7 +72,7 @@ _SIGNATURES = {
     "gsl_knn_query": (c_int, [P, c_int, P, P, c_int, P, P, c_size_t, P]),
     "gsl_fused_project_bwd": (c_int, [P, P, P, P, P, c_int, c_int, P, P, c_int, c_int, c_int, c_float, c_int, c_int,
                                       P, P, P, P, P, P, P, P, P, P, P, c_size_t, c_int, P, P, P, P, c_int, c_int,
-                                      c_int, c_int, c_int64, P, P, c_int, P]),
+                                      c_int, c_int, c_int64, P, P, c_int, P, P]),
     "gsl_tiny_raster_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int64,
                                     P, P, P, P, P, P, P, c_int, c_int, P, c_int, P, c_float, c_float, P, P, P]),
     "gsl_isect_emit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),

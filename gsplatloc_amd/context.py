@@ -35,8 +35,14 @@ class RenderContext:
                  radius_clip: float = 0.0, antialiased: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
                  capacity: Optional[int] = None, full_grads: bool = True,
                  pixel_rows: Optional[Tuple[int, int]] = None, staging: str = "fp32", deterministic: bool = False,
-                 sort_in_forward: bool = False):
+                 sort_in_forward: bool = False, reorder: Optional[bool] = None):
         self.lib = load_library()
+        # reorder (tile-order placement, see calibrate()): True / False, or None = decide at calibration -- on when the
+        # Gaussians are numerous and NOT already in a screen-coherent order (a back-projected depth frame is)
+        self.reorder = reorder
+        self.order_ids = self.storage_of = None  # int32[N]: original index of a storage slot / slot of an original index
+        self._placed = None       # context-owned copies of the per-Gaussian inputs in storage order
+        self._placed_key = None   # (data_ptr, version) of the caller's tensors they were made from
         # sort_in_forward (callers whose every forward is followed by a backward: the tracker): the compositing forward
         # sorts its own tile's bin -- no gsl_fused_bin launch -- whenever the frame allows it (sorts_in_forward())
         self.sort_in_forward = bool(sort_in_forward)
@@ -96,10 +102,13 @@ class RenderContext:
             if self.rgb:
                 shape = (N, self.K_sh, 3) if self.sh_degree >= 0 else (N, 3)
                 self.v_colors = torch.zeros(*shape, dtype=f32, device=dev)
+                self.vc_state = torch.ones(1, dtype=i32, device=dev)  # "v_colors holds zeros only" (gsl_fused_project_bwd)
             else:
                 self.v_colors = None
         else:
             self.v_means = self.v_quats = self.v_scales = self.v_opacities = self.v_colors = None
+        if not hasattr(self, "vc_state"):
+            self.vc_state = None
         self.capacity = 0
         self.tiny = False
         self.flags = self.status[0:4]
@@ -131,9 +140,14 @@ class RenderContext:
             self.vrow = torch.zeros(self.capacity, 16, dtype=torch.float32, device=self.device)
 
     def calibrate(self, means, quats, scales, opacities, colors, viewmat, K, headroom: float = 1.3) -> int:
-        """One synchronising projection pass to size the intersection buffers and the per-tile bins."""
+        """One synchronising projection pass to size the intersection buffers and the per-tile bins -- and, for Gaussians
+        in no screen-coherent order, to choose their tile-order placement (_choose_placement)."""
         self.bins, self.bin_cap = None, 0  # two-pass binning for this measuring pass
+        self.order_ids = self.storage_of = self._placed = self._placed_key = None
         self._project(means, quats, scales, opacities, colors, viewmat, K)
+        if self._choose_placement():
+            # records in storage order (what _choose_backward looks at); same lists, same sizes
+            self._project(*self._place(means, quats, scales, opacities, colors), viewmat, K)
         n = int(self.n_is.item())
         self._alloc_isects(int(n * headroom) + 1024)
         sizes = (self.offs[1:] - self.offs[:-1]) if self.n_tiles else self.offs[:0]
@@ -142,6 +156,61 @@ class RenderContext:
         self._choose_backward()
         self._alloc_long(sizes, headroom)
         return n
+
+    # ------------------------------------------------------------------ tile-order placement
+    REORDER_MIN_N = 65536  # below this the whole record set sits in one XCD's L2 anyway
+
+    def _choose_placement(self) -> bool:
+        """Tile-order placement of the Gaussians, once per frame (the inputs are static while the pose is optimised:
+        /root/reference/src/my_gsplat/model.py:137-175).  With Gaussians in random order every list entry's record gather
+        pulls its own 64-128-byte line (3.5-7 x the algorithmic bytes of the compositing forward) and
+        the projection scatters its bin writes over the whole image.  Here the context keeps its OWN copies of the inputs
+        sorted (stably) by the tile of the projected centre at the calibration pose; `order_ids[slot]` is the original
+        index and stays the low word of the sort key, so depth ties break exactly as in the caller's order -- the lists
+        are the unpermuted run's lists with every id relabelled (`storage_of`), images and last_ids bit-identical
+        (tests/test_gpu_reorder.py).  Everything per Gaussian the context owns (records, radii, gradient buffers) is then
+        in STORAGE order: use grads_in_input_order() / order_ids."""
+        want = self.reorder
+        if want is None:
+            want = (os.environ.get("GSLOC_REORDER", "1") != "0" and self.N >= self.REORDER_MIN_N
+                    and not self._screen_coherent_order())
+        if not want or self.N < 2:
+            return False
+        assert not self.deterministic, "deterministic mode finds a Gaussian's rows by key: no tile-order placement"
+        assert self.tiles_per_gauss is None, "tiles_per_gauss is a per-Gaussian output in caller order: reorder=False"
+        vis = self.Q1[:, 3] > 0
+        tx = torch.clamp(torch.floor(self.Q0[:, 0] / 16.0), 0, self.tw - 1).to(torch.int64)
+        ty = torch.clamp(torch.floor(self.Q0[:, 1] / 16.0), 0, self.th - 1).to(torch.int64)
+        tile = torch.where(vis, ty * self.tw + tx, torch.full_like(tx, self.n_tiles))  # culled Gaussians last
+        perm = torch.sort(tile, stable=True).indices
+        self.order_ids = perm.to(torch.int32).contiguous()
+        self.storage_of = torch.empty_like(self.order_ids)
+        self.storage_of[perm] = torch.arange(self.N, dtype=torch.int32, device=self.device)
+        self._perm64 = perm.contiguous()
+        return True
+
+    def _place(self, means, quats, scales, opacities, colors):
+        """The caller's per-Gaussian inputs -> the context's copies in storage order (re-gathered only when the caller
+        passes other tensors, or has written to them in place, since the last call)."""
+        if self.order_ids is None:
+            return means, quats, scales, opacities, colors
+        srcs = (means, quats, scales, opacities) + ((colors,) if (self.rgb and colors is not None) else ())
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in srcs)
+        if self._placed_key != key:
+            if self._placed is None or any(p.shape != t.shape for p, t in zip(self._placed, srcs)):
+                self._placed = tuple(torch.empty_like(t) for t in srcs)
+            for p, t in zip(self._placed, srcs):
+                torch.index_select(t.detach(), 0, self._perm64, out=p)
+            self._placed_key = key
+        pl = self._placed
+        return pl[0], pl[1], pl[2], pl[3], (pl[4] if len(pl) > 4 else colors)
+
+    def grads_in_input_order(self, grads: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """backward()'s per-Gaussian gradients in the CALLER's order (new tensors; `viewmat` passed through)."""
+        if self.storage_of is None:
+            return grads
+        idx = self.storage_of.to(torch.int64)
+        return {k: (v if (k == "viewmat" or v is None) else torch.index_select(v, 0, idx)) for k, v in grads.items()}
 
     def _alloc_long(self, sizes: Tensor, headroom: float) -> None:
         """Long-list mode: on when some tile list comes near LONG_MIN entries (deterministic mode keeps its own
@@ -309,7 +378,7 @@ class RenderContext:
             ptr(self.Q0), ptr(self.Q1), ptr(self.Q2), ptr(self.comps), ptr(self.tiles_per_gauss), ptr(self.offs),
             ptr(self.n_is),
             ptr(self.ws), self.ws_bytes, ptr(self.Qh), ptr(self.bins), self.bin_cap, ptr(self.flags),
-            current_stream()), "gsl_fused_project")
+            ptr(self.order_ids), current_stream()), "gsl_fused_project")
 
     def _bin(self) -> None:
         if self.sorts_in_forward():
@@ -318,13 +387,14 @@ class RenderContext:
                                      tile_n_bits(self.n_tiles), ptr(self.offs), self.capacity, ptr(self.keys),
                                      ptr(self.flatten_ids), None, ptr(self.ws), self.ws_bytes, int(self.deterministic),
                                      ptr(self.bins), self.bin_cap, ptr(self.n_is), ptr(self.flags),
-                                     self.long_min if self.bins is not None else 0, current_stream()),
+                                     self.long_min if self.bins is not None else 0, ptr(self.order_ids),
+                                     ptr(self.storage_of), current_stream()),
               "gsl_fused_bin")
         if self.long_min and self.bins is not None:  # the long lists: sorted by several workgroups
             check(self.lib.gsl_long_sort(ptr(self.offs), self.tw, self.th, self.ty0, self.ty1, self.capacity,
                                          ptr(self.bins), self.bin_cap, ptr(self.keys), ptr(self.flatten_ids),
                                          self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
-                                         self.long_passes, current_stream()), "gsl_long_sort")
+                                         self.long_passes, ptr(self.storage_of), current_stream()), "gsl_long_sort")
 
     def _raster_fwd(self) -> None:
         sif = self.sorts_in_forward()
@@ -337,7 +407,7 @@ class RenderContext:
                                             ptr(self.hit_counts) if self.record_hits else None, self.long_min,
                                             ptr(self.bins) if sif else None, self.bin_cap if sif else 0,
                                             ptr(self.n_is) if sif else None, ptr(self.flags) if sif else None,
-                                            current_stream()),
+                                            ptr(self.storage_of) if sif else None, current_stream()),
               "gsl_fused_raster_fwd")
         if not sif:  # (sorting forward: the counters stay set until the backward clears them)
             self._counters_dirty = False
@@ -395,7 +465,8 @@ class RenderContext:
             ptr(self.v_means) if full else None, ptr(self.v_quats) if full else None,
             ptr(self.v_scales) if full else None, ptr(self.v_opacities) if full else None,
             ptr(self.v_colors) if (full and self.rgb) else None, ptr(self.v_viewmat), ptr(self.ws), self.ws_bytes,
-            self.n_tiles, *det, *tiny, int(reduce), current_stream()), "gsl_fused_project_bwd")
+            self.n_tiles, *det, *tiny, int(reduce), ptr(self.vc_state) if (full and self.rgb) else None,
+            current_stream()), "gsl_fused_project_bwd")
 
     # ------------------------------------------------------------------ forward / backward
     def forward(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Optional[Tensor],
@@ -403,6 +474,7 @@ class RenderContext:
         """Render into the context's buffers (valid until the next forward).  Inputs: contiguous fp32
         device tensors; viewmat [4,4], K [3,3].  No allocation, no host sync."""
         assert self.keys is not None, "call calibrate() (or pass capacity=) before forward()"
+        means, quats, scales, opacities, colors = self._place(means, quats, scales, opacities, colors)
         self._project(means, quats, scales, opacities, colors, viewmat, K)
         self._bin()
         self._raster_fwd()
@@ -415,6 +487,7 @@ class RenderContext:
         binning (cheap kernels), before compositing.  Returns None and the rendered buffers are valid, or the reason
         the lists are incomplete (compositing skipped: grow the buffers / calibrate() and call again)."""
         assert self.keys is not None, "call calibrate() (or pass capacity=) before forward()"
+        means, quats, scales, opacities, colors = self._place(means, quats, scales, opacities, colors)
         self._project(means, quats, scales, opacities, colors, viewmat, K)
         self._bin()
         why = self.overflow_status()
@@ -449,7 +522,9 @@ class RenderContext:
     def backward(self, v_render: Tensor, v_alphas: Tensor, full: Optional[bool] = None,
                  reduce_viewmat: bool = True, tracking_loss=None) -> Dict[str, Tensor]:
         """vjp of the last forward.  Returns the context's gradient buffers: always ``viewmat``
-        ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors.
+        ([4,4], row 3 zero); with full gradients also means/quats/scales/opacities/colors -- in STORAGE order when the
+        context placed the Gaussians in tile order (``order_ids`` is not None: row p belongs to the caller's Gaussian
+        order_ids[p]; grads_in_input_order() un-permutes).
         ``reduce_viewmat=False`` skips the last launch: the pose gradient stays as ``viewmat_rows()`` for
         gsl_pose_step / gsl_pack_pose_reduce, which sum them in the same fixed order (``viewmat`` is then stale).
         ``tracking_loss=(depth_gt [H,W], depth_lambda, edge_lambda, partials [tiles,2])`` (can_fuse_tracking_loss()):
@@ -488,6 +563,8 @@ class _CtxRender(torch.autograd.Function):
         ni = ctx.needs_input_grad
         full = rc.full_grads and any(ni[1:6])
         g = rc.backward(v_render.contiguous(), v_alphas.contiguous(), full=full)
+        if full:
+            g = rc.grads_in_input_order(g)
         return (None, g["means"] if (full and ni[1]) else None, g["quats"] if (full and ni[2]) else None,
                 g["scales"] if (full and ni[3]) else None, g["opacities"] if (full and ni[4]) else None,
                 g["colors"] if (full and ni[5] and rc.rgb) else None, g["viewmat"] if ni[6] else None, None)
@@ -514,6 +591,7 @@ def time_stages(rc: RenderContext, inputs, v_render: Tensor, v_alphas: Tensor, f
         e.record()
         return e
 
+    inputs = tuple(rc._place(*inputs[:5])) + tuple(inputs[5:])
     for it in range(steps + 2):
         marks = [ev()]
         rc._project(*inputs)

@@ -357,7 +357,8 @@ __device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* 
 template <int LK>
 __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int lane,
                                                uint64_t* __restrict__ keys_out, int32_t* __restrict__ flatten_ids,
-                                               int64_t* __restrict__ isect_ids, int64_t cam_enc) {
+                                               int64_t* __restrict__ isect_ids, int64_t cam_enc,
+                                               const int32_t* __restrict__ storage_of) {
   constexpr int KPT = 1 << LK;
   uint64_t k[KPT];
   int e0 = lane * KPT;
@@ -368,7 +369,7 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
   for (int r = 0; r < KPT; ++r)
     if (e0 + r < n) {
       uint64_t v = k[r];
-      flatten_ids[s + e0 + r] = (int32_t)(uint32_t)v;
+      flatten_ids[s + e0 + r] = list_id(storage_of, v);
       if (isect_ids) isect_ids[s + e0 + r] = cam_enc | ((int64_t)t << 32) | (int64_t)(v >> 32);
       if (keys_out) keys_out[s + e0 + r] = v;
     }
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
                                                    int64_t* __restrict__ isect_ids, int64_t cam_enc,
                                                    int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap,
                                                    const int32_t* __restrict__ counts, int32_t* __restrict__ n_isects,
-                                                   int32_t* __restrict__ flags, int long_min) {
+                                                   int32_t* __restrict__ flags, int long_min,
+                                                   const int32_t* __restrict__ storage_of) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
   __shared__ int s_scan[8];
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -443,10 +445,10 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
     // into registers before any lane writes)
     uint64_t* kout = write_sorted_keys ? keys : nullptr;
     if (n > 0 && n <= GSL_SORT_WAVE_MAX) {
-      if (n <= 256) wave_sort_tile<2>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
-      else if (n <= 512) wave_sort_tile<3>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
-      else if (n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
-      else wave_sort_tile<5>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc);
+      if (n <= 256) wave_sort_tile<2>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
+      else if (n <= 512) wave_sort_tile<3>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
+      else if (n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
+      else wave_sort_tile<5>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
     }
   }
   // rare: lists too long for one wave, sorted in place by the whole workgroup, one after the other
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
     bitonic_sort_long(src, n, skeys, tid);
     for (int i = tid; i < n; i += 256) {
       uint64_t k = src[i];
-      flatten_ids[s + i] = (int32_t)(uint32_t)k;
+      flatten_ids[s + i] = list_id(storage_of, k);
       if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
       if (write_sorted_keys && bins) keys[s + i] = k;
     }
@@ -583,7 +585,8 @@ __device__ __forceinline__ int merge_diag_wave(const uint64_t* __restrict__ A, i
 // pass p: runs of (GSL_SORT_SEG << p) keys -> runs of twice that.  src / dst: the packed key array and the bins, alternating.
 __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ tile_offsets, long long capacity,
                                                    uint64_t* __restrict__ bins, int bin_cap, uint64_t* __restrict__ keys,
-                                                   int pass, int last, int32_t* __restrict__ flatten_ids, LongWs w) {
+                                                   int pass, int last, int32_t* __restrict__ flatten_ids, LongWs w,
+                                                   const int32_t* __restrict__ storage_of) {
   __shared__ uint64_t sk[GSL_SORT_SEG];
   __shared__ int s_split[4];
   int g = blockIdx.x;
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(64) void k_long_merge(const int32_t* __restrict__ t
     if (ib >= nb || (ia < na && sk[ia] <= sk[na + ib])) v = sk[ia++];
     else v = sk[na + ib++];
     dst[pair_start + o + d] = v;
-    if (last) flatten_ids[s + pair_start + o + d] = (int32_t)(uint32_t)v;
+    if (last) flatten_ids[s + pair_start + o + d] = list_id(storage_of, v);
   }
 }
 
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(256) void k_tile_sort_wg(int32_t* __restrict__ tile
                                                       int64_t* __restrict__ isect_ids, int64_t cam_enc,
                                                       int write_sorted_keys, uint64_t* __restrict__ bins, int bin_cap,
                                                       const int32_t* __restrict__ counts, int32_t* __restrict__ n_isects,
-                                                      int32_t* __restrict__ flags, int long_min) {
+                                                      int32_t* __restrict__ flags, int long_min,
+                                                      const int32_t* __restrict__ storage_of) {
   __shared__ uint64_t skeys[GSL_SORT_LDS_CAP];
   __shared__ int s_scan[5];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -683,15 +687,15 @@ __global__ __launch_bounds__(256) void k_tile_sort_wg(int32_t* __restrict__ tile
   uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
   uint64_t* kout = write_sorted_keys ? keys : nullptr;
   if (n <= 1024) {
-    wg_sort_tile<2>(src, n, s, t, tid, skeys, kout, flatten_ids, isect_ids, cam_enc);
+    wg_sort_tile<2>(src, n, s, t, tid, skeys, kout, flatten_ids, isect_ids, cam_enc, storage_of);
   } else if (n <= 2048) {
-    wg_sort_tile<3>(src, n, s, t, tid, skeys, kout, flatten_ids, isect_ids, cam_enc);
+    wg_sort_tile<3>(src, n, s, t, tid, skeys, kout, flatten_ids, isect_ids, cam_enc, storage_of);
   } else {
     if (long_min > 0 && bins && n > long_min) return;  // sorted by several workgroups: gsl_long_sort
     bitonic_sort_long(src, n, skeys, tid);
     for (int i = tid; i < n; i += 256) {
       uint64_t k = src[i];
-      flatten_ids[s + i] = (int32_t)(uint32_t)k;
+      flatten_ids[s + i] = list_id(storage_of, k);
       if (isect_ids) isect_ids[s + i] = cam_enc | ((int64_t)t << 32) | (int64_t)(k >> 32);
       if (write_sorted_keys && bins) keys[s + i] = k;
     }
@@ -765,7 +769,8 @@ extern "C" int gsl_isect_fill(const float* means2d, const int32_t* radii, const 
 extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                                   int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
-                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles, void* stream);
+                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles,
+                                  const int32_t* storage_of, void* stream);
 
 extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                              uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
@@ -774,7 +779,7 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
   if (n_strip_tiles == 0 || capacity == 0) return GSL_OK;
   if (!sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
   return gsl_tile_sort_keys(const_cast<int32_t*>(tile_offsets), tile_begin, n_strip_tiles, capacity, sort_keys, flatten_ids,
-                            isect_ids, cam_enc, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, stream);
+                            isect_ids, cam_enc, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
 // gsl_tile_sort that can also leave the sorted (depth bits, id) keys in sort_keys and read the unsorted keys from
@@ -782,7 +787,8 @@ extern "C" int gsl_tile_sort(const int32_t* tile_offsets, int tile_begin, int n_
 extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                                   int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
-                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles, void* stream) {
+                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles,
+                                  const int32_t* storage_of, void* stream) {
   if (!tile_offsets || tile_begin < 0 || n_strip_tiles < 0 || capacity < 0) return GSL_ERR_BAD_ARG;
   if (counts && (!bins || tile_begin != 0)) return GSL_ERR_BAD_ARG;  // the scan runs over all tiles, bins only
   if (n_strip_tiles == 0 || (capacity == 0 && !counts)) return GSL_OK;
@@ -791,7 +797,7 @@ extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_s
   // (occupied_tiles: the tiles that can hold entries -- a strip's, when the launch runs over all tiles of the image)
   const int occ = occupied_tiles > 0 ? occupied_tiles : n_strip_tiles;
   const long long mean_list = capacity / (long long)occ;
-  const char* force = getenv("GSL_DEV_TILE_SORT");  // dev / test switch: "wave" / "wg"
+  static const char* const force = getenv("GSL_DEV_TILE_SORT");  // dev / test switch: "wave" / "wg" (read once)
   // (a latency matter: with more tiles than the chip has room for wave sorts at once, one tile per wave keeps more
   // lists in flight and is as fast or faster -- X: 159 against 169 us; with a strip's few hundred tiles the workgroup
   // kernel's shorter critical path decides)
@@ -799,11 +805,11 @@ extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_s
   if (wg)
     hipLaunchKernelGGL(gsl::k_tile_sort_wg, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
                        tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
-                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min);
+                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min, storage_of);
   else
     hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
                        tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
-                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min);
+                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min, storage_of);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }
@@ -836,7 +842,8 @@ extern "C" int gsl_isect_offsets(const int64_t* isect_ids, int64_t n_isects, int
 // Multi-workgroup sort of the long tile lists (binned mode; see k_long_sort_seg).  Call after gsl_fused_bin(long_min).
 extern "C" int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
                              uint64_t* bins, int bin_cap, uint64_t* sort_keys, int32_t* flatten_ids, int long_min,
-                             void* long_ws, size_t long_ws_bytes, int max_seg, int passes, void* stream) {
+                             void* long_ws, size_t long_ws_bytes, int max_seg, int passes, const int32_t* storage_of,
+                             void* stream) {
   if (tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0 || long_min <= 0 ||
       max_seg <= 0 || passes < 0 || passes > 12 || bin_cap <= 0)
     return GSL_ERR_BAD_ARG;
@@ -851,7 +858,7 @@ extern "C" int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h
                      bin_cap, sort_keys, w);
   for (int p = 0; p < passes; ++p)
     hipLaunchKernelGGL(gsl::k_long_merge, dim3(max_seg), dim3(64), 0, st, tile_offsets, (long long)capacity, bins, bin_cap,
-                       sort_keys, p, p == passes - 1 ? 1 : 0, flatten_ids, w);
+                       sort_keys, p, p == passes - 1 ? 1 : 0, flatten_ids, w, storage_of);
   GSL_CHECK_LAUNCH();
   return GSL_OK;
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     int32_t* __restrict__ radii, float4* __restrict__ Q0, float4* __restrict__ Q1, float4* __restrict__ Q2,
     float* __restrict__ comps, int32_t* __restrict__ tiles_per_gauss, int32_t* __restrict__ tile_counts,
     uint4* __restrict__ Qh, uint64_t* __restrict__ bins, int bin_cap, int32_t* __restrict__ bin_state,
-    int32_t* __restrict__ flags) {
+    int32_t* __restrict__ flags, const int32_t* __restrict__ order_ids) {
   extern __shared__ int s_hist[];
   int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
   // Counter contract of the binned mode: the tile counters must be zero on entry -- the compositing forward of the
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
       ymin = max(ymin, ty0);
       ymax = min(ymax, ty1);
       if (ymax < ymin) ymax = ymin;
-      key = ((uint64_t)__float_as_uint(o0.z) << 32) | (uint32_t)i;
+      key = ((uint64_t)__float_as_uint(o0.z) << 32) | (uint32_t)(order_ids ? order_ids[i] : i);
     }
     if (tiles_per_gauss) tiles_per_gauss[i] = (xmax - xmin) * (ymax - ymin);
   }
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_ftile_scan(int32_t* __restrict__ count
 __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
     const float4* __restrict__ Q0, const int32_t* __restrict__ radii, int N, int tile_w, int tile_h, int ty0, int ty1,
     const int32_t* __restrict__ tile_offsets, int32_t* __restrict__ cursors, long long capacity,
-    uint64_t* __restrict__ keys) {
+    uint64_t* __restrict__ keys, const int32_t* __restrict__ order_ids) {
   extern __shared__ int s_mem[];
   int nst = (ty1 - ty0) * tile_w, tbase = ty0 * tile_w;
   int* s_cnt = s_mem;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fscatter(
       ymin = max(ymin, ty0);
       ymax = min(ymax, ty1);
       if (ymax < ymin) ymax = ymin;
-      key = ((uint64_t)__float_as_uint(q0.z) << 32) | (uint32_t)i;
+      key = ((uint64_t)__float_as_uint(q0.z) << 32) | (uint32_t)(order_ids ? order_ids[i] : i);
     }
   }
   for (int y = ymin; y < ymax; ++y)
@@ -681,10 +681,16 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
     float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
     float* __restrict__ partials, const float4* __restrict__ vrow, const uint64_t* __restrict__ skeys,
     const int32_t* __restrict__ tile_offsets, const float4* __restrict__ Q0, int tile_w, int tile_h, int ty0, int ty1,
-    long long capacity, float4* __restrict__ trec, const float* __restrict__ vcT) {
+    long long capacity, float4* __restrict__ trec, const float* __restrict__ vcT, int32_t* __restrict__ vc_state) {
   constexpr bool RGB = D >= 3;
   int i = blockIdx.x * 256 + threadIdx.x;
   Cam cam = load_cam(V, Kmat);
+  // vc_state (may be NULL): 1 = the caller's v_colors buffer is known to hold zeros only (it is the same buffer call after
+  // call, and nobody has written a non-zero since); a Gaussian without a colour gradient -- every Gaussian, under
+  // GsplatLoc's depth-only loss -- then skips its 48 bytes of zero stores.  A thread that writes a real gradient marks
+  // the buffer dirty (2); k_freduce_viewmat, which runs after the whole grid, turns "nobody wrote a non-zero in a launch
+  // that stored everything" into 1 again.
+  const bool vc_zero = FULL && RGB && vc_state && *vc_state == 1;
   // tiny-splat backward, pass 2 fused in: four lanes per Gaussian fold its 4x4 slab of (w, alpha*T) records into the
   // gradient row, which stays in LDS for the thread that owns the Gaussian (no row round trip, no gather launch)
   __shared__ float4 srow[256][3];
@@ -802,6 +808,7 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
       for (int k = 0; k < nK; ++k) {
         sk[k] = cf[3 * k] * vrgb[0] + cf[3 * k + 1] * vrgb[1] + cf[3 * k + 2] * vrgb[2];
         if (FULL) {
+          if (k == 0 && vc_state) *vc_state = 2;
           v_colors[((size_t)i * K_sh + k) * 3] = Y[k] * vrgb[0];
           v_colors[((size_t)i * K_sh + k) * 3 + 1] = Y[k] * vrgb[1];
           v_colors[((size_t)i * K_sh + k) * 3 + 2] = Y[k] * vrgb[2];
@@ -830,8 +837,12 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
     v_opacities[i] = vop;
     if (RGB && !sh_live) {
       if (sh_degree < 0) {
-        v_colors[3 * (size_t)i] = vrgb[0]; v_colors[3 * (size_t)i + 1] = vrgb[1]; v_colors[3 * (size_t)i + 2] = vrgb[2];
-      } else {
+        const bool nz = vrgb[0] != 0.f || vrgb[1] != 0.f || vrgb[2] != 0.f;
+        if (nz && vc_state) *vc_state = 2;
+        if (nz || !vc_zero) {
+          v_colors[3 * (size_t)i] = vrgb[0]; v_colors[3 * (size_t)i + 1] = vrgb[1]; v_colors[3 * (size_t)i + 2] = vrgb[2];
+        }
+      } else if (!vc_zero) {
         // (12 coefficients = 48 bytes per Gaussian for SH degree 1: three 16-byte stores instead of twelve strided
         // 4-byte ones; any other band count keeps the loop)
         if (K_sh == 4) {
@@ -892,11 +903,14 @@ __global__ __launch_bounds__(256) void k_freduce_rows(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict__ partials, int nb,
                                                         const float* __restrict__ V, const float* __restrict__ Kmat,
-                                                        float* __restrict__ v_viewmat) {
+                                                        float* __restrict__ v_viewmat, int32_t* __restrict__ vc_state) {
   __shared__ float red[4][15];
   __shared__ float tot[15];
   float v = reduce_viewmat_rows(partials, nb, V, Kmat, red, tot);
   if (threadIdx.x < 16) v_viewmat[threadIdx.x] = v;
+  // (see k_fproject_bwd) 2: a real colour gradient was written in the launch before this one -> unknown; otherwise every
+  // Gaussian's slot holds zeros now
+  if (vc_state && threadIdx.x == 0) *vc_state = (*vc_state == 2) ? 0 : 1;
 }
 
 }  // namespace gsl
@@ -928,7 +942,8 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
                                  float radius_clip, int antialiased, int tile_w, int tile_h, int ty0, int ty1,
                                  int32_t* radii, float* Q0, float* Q1, float* Q2, float* compensations,
                                  int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
-                                 size_t ws_bytes, void* Qh, void* bins, int bin_cap, int32_t* flags, void* stream) {
+                                 size_t ws_bytes, void* Qh, void* bins, int bin_cap, int32_t* flags,
+                                 const int32_t* order_ids, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1)
     return GSL_ERR_BAD_ARG;
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
@@ -954,7 +969,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
                      sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,        \
                      antialiased, tile_w, tile_h, ty0, ty1, radii, (float4*)Q0, (float4*)Q1, (float4*)Q2,             \
                      compensations, tiles_per_gauss, counts, (uint4*)Qh, (uint64_t*)bins, bin_cap,                   \
-                     bins ? gsl_bin_state(ws, n_tiles) : (int32_t*)nullptr, flags)
+                     bins ? gsl_bin_state(ws, n_tiles) : (int32_t*)nullptr, flags, order_ids)
     if (Q2) { if (bins) CALL_P(true, true); else CALL_P(true, false); }
     else { if (bins) CALL_P(false, true); else CALL_P(false, false); }
 #undef CALL_P
@@ -971,13 +986,14 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
 extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_strip_tiles, int64_t capacity,
                                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, int64_t cam_enc,
                                   int write_sorted_keys, uint64_t* bins, int bin_cap, const int32_t* counts,
-                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles, void* stream);
+                                  int32_t* n_isects, int32_t* flags, int long_min, int occupied_tiles,
+                                  const int32_t* storage_of, void* stream);
 
 extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0, int ty1,
                              int tile_n_bits, int32_t* tile_offsets, int64_t capacity, uint64_t* sort_keys,
                              int32_t* flatten_ids, int64_t* isect_ids, void* ws, size_t ws_bytes,
                              int write_sorted_keys, void* bins, int bin_cap, int32_t* n_isects, int32_t* flags,
-                             int long_min, void* stream) {
+                             int long_min, const int32_t* order_ids, const int32_t* storage_of, void* stream) {
   if (N < 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 || capacity < 0)
     return GSL_ERR_BAD_ARG;
   int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
@@ -990,7 +1006,7 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
     if (capacity > 0 && (!sort_keys || !flatten_ids)) return GSL_ERR_BAD_ARG;
     return gsl_tile_sort_keys(tile_offsets, 0, n_tiles, capacity, sort_keys, flatten_ids, isect_ids, 0,
                               write_sorted_keys, (uint64_t*)bins, bin_cap, (const int32_t*)ws, n_isects, flags,
-                              write_sorted_keys ? 0 : long_min, nst, stream);
+                              write_sorted_keys ? 0 : long_min, nst, storage_of, stream);
   }
   if (N == 0 || capacity == 0 || nst == 0) return GSL_OK;
   if (!Q0 || !radii || !sort_keys || !flatten_ids) return GSL_ERR_BAD_ARG;
@@ -999,10 +1015,10 @@ extern "C" int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int t
   int32_t* cursors = (int32_t*)ws + n_tiles;
   hipLaunchKernelGGL(gsl::k_fscatter, dim3((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), dim3(GSL_F_BIN_THREADS),
                      (size_t)2 * nst * sizeof(int), st, (const float4*)Q0, radii, N, tile_w, tile_h, ty0, ty1,
-                     tile_offsets, cursors, (long long)capacity, sort_keys);
+                     tile_offsets, cursors, (long long)capacity, sort_keys, order_ids);
   GSL_CHECK_LAUNCH();
   return gsl_tile_sort_keys(tile_offsets, ty0 * tile_w, nst, capacity, sort_keys, flatten_ids, isect_ids, 0,
-                            write_sorted_keys, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, stream);
+                            write_sorted_keys, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, storage_of, stream);
 }
 
 // defined in raster_g16.hip
@@ -1090,7 +1106,7 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
                                      float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
                                      const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0,
                                      int tile_w, int tile_h, int ty0, int ty1, int64_t capacity, float* tiny_trec,
-                                     const float* tiny_vcT, int reduce_viewmat, void* stream) {
+                                     const float* tiny_vcT, int reduce_viewmat, int32_t* v_colors_state, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || n_tiles <= 0) return GSL_ERR_BAD_ARG;
   if (reduce_viewmat && !v_viewmat) return GSL_ERR_BAD_ARG;
   if (channels != 1 && channels != 3 && channels != 4) return GSL_ERR_BAD_ARG;
@@ -1115,12 +1131,13 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
   // one row of 15 sums per workgroup; reduce_viewmat = 0 leaves them for gsl_pose_step / gsl_pack_pose_reduce
   float* partials = (float*)((char*)ws + gsl_vm_rows_offset(n_tiles));
   int grid = (N + 255) / 256;
+  int32_t* vcs = (full && channels >= 3) ? v_colors_state : nullptr;
 #define CALL_PB(FF, DD)                                                                                          \
   hipLaunchKernelGGL((gsl::k_fproject_bwd<FF, DD>), dim3(grid), dim3(256), 0, st, means, quats, scales, opacities, \
                      colors, sh_degree, K_sh, viewmat, K, N, width, height, eps2d, antialiased, radii,             \
                      (const float4*)Q1, compensations, (float4*)vacc, v_means, v_quats, v_scales, v_opacities,    \
                      v_colors, partials, (const float4*)vrow, sorted_keys, tile_offsets, (const float4*)Q0, tile_w,   \
-                     tile_h, ty0, ty1, (long long)capacity, (float4*)tiny_trec, tiny_vcT)
+                     tile_h, ty0, ty1, (long long)capacity, (float4*)tiny_trec, tiny_vcT, vcs)
   if (full) {
     if (channels == 1) CALL_PB(true, 1); else if (channels == 3) CALL_PB(true, 3); else CALL_PB(true, 4);
   } else {
@@ -1132,9 +1149,9 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     if (grid > 8192) {  // two stages (fixed order either way)
       float* stage = partials + (size_t)grid * 16;
       hipLaunchKernelGGL(gsl::k_freduce_rows, dim3(GSL_VM_STAGE_ROWS), dim3(256), 0, st, partials, grid, stage);
-      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, stage, GSL_VM_STAGE_ROWS, viewmat, K, v_viewmat);
+      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, stage, GSL_VM_STAGE_ROWS, viewmat, K, v_viewmat, vcs);
     } else {
-      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat);
+      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat, vcs);
     }
     GSL_CHECK_LAUNCH();
   }

@@ -137,6 +137,16 @@ __device__ __forceinline__ void load_record(const float4* __restrict__ Q0, const
   }
 }
 
+// Tile-order placement of the Gaussians (RenderContext(reorder=True)): the caller stores its Gaussians
+// sorted by the tile of their centre, once per frame, so that the record gathers of a tile's list fall on a few contiguous
+// runs.  The list ORDER must not change with the placement -- depth ties break by Gaussian index -- so the
+// low key word stays the Gaussian's ORIGINAL index (order_ids[storage slot], given to the projection) and the sorts translate
+// it to the storage slot (storage_of[original index]) only when they write the list.  Both NULL: identity.
+__device__ __forceinline__ int32_t list_id(const int32_t* __restrict__ storage_of, uint64_t key) {
+  uint32_t g = (uint32_t)key;
+  return storage_of ? storage_of[g] : (int32_t)g;
+}
+
 // DPP lane exchange (no LDS traffic).  Lanes a row_mask disables contribute 0.
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_get(float v) {

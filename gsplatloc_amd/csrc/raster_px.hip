@@ -295,6 +295,7 @@ struct FwdSort {
   int32_t* n_isects;      // out (total)
   int32_t* flags;         // flags[1], flags[2]: a tile outgrew its bin
   int bin_cap;
+  const int32_t* storage_of;  // tile-order placement (gsloc_common.h, list_id); may be NULL
 };
 template <int SORT> struct FwdListPtr { typedef const int32_t* __restrict__ type; };
 template <> struct FwdListPtr<2> { typedef const int32_t* type; };  // (the kernel writes what these point to)
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
     int n = (int)max(e0 - s0, (long long)0);
     if (n > 256) {
       wg_sort_tile<SORT>(fs.bins + (size_t)tile * (size_t)fs.bin_cap, n, s0, tile, tid, reinterpret_cast<uint64_t*>(smem),
-                         nullptr, fs.flatten_ids, nullptr, 0);
+                         nullptr, fs.flatten_ids, nullptr, 0, fs.storage_of);
     } else if (n > 0 && wv == 0) {  // a short list: one wave's registers, no merge passes
       const uint64_t* src = fs.bins + (size_t)tile * (size_t)fs.bin_cap;
       uint64_t k[4];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_praster_fwd(
       wave_sort_regs<2>(k, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (lane * 4 + r < n) fs.flatten_ids[s0 + lane * 4 + r] = (int32_t)(uint32_t)k[r];
+        if (lane * 4 + r < n) fs.flatten_ids[s0 + lane * 4 + r] = list_id(fs.storage_of, k[r]);
     }
     __syncthreads();  // the list is in flatten_ids (this workgroup's own stores: visible after the barrier's fence)
     sorted_rs = s0;
@@ -843,7 +844,8 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
                                  const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
                                  int32_t* last_ids, int row0, int row1, const void* Qh, void* binned_ws,
                                  uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min, void* sort_bins,
-                                 int bin_cap, int32_t* n_isects, int32_t* flags, void* stream) {
+                                 int bin_cap, int32_t* n_isects, int32_t* flags, const int32_t* storage_of,
+                                 void* stream) {
   if (width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1 ||
       capacity < 0 || row0 < 0 || row0 > row1)
     return GSL_ERR_BAD_ARG;
@@ -862,7 +864,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   hipStream_t st = (hipStream_t)stream;
   int nblk = (ty1 - ty0) * tile_w;
   gsl::FwdSort fs{(uint64_t*)sort_bins, (const int32_t*)binned_ws, const_cast<int32_t*>(tile_offsets),
-                  const_cast<int32_t*>(flatten_ids), n_isects, flags, bin_cap};
+                  const_cast<int32_t*>(flatten_ids), n_isects, flags, bin_cap, storage_of};
   // (sorting variant: the counters are still being added up by other workgroups -- the backward clears them)
   int32_t* clear_counts = sort ? nullptr : (int32_t*)binned_ws;
   int32_t* clear_state = sort ? nullptr : gsl_fused_bin_state(binned_ws, tile_w * tile_h);

@@ -94,7 +94,7 @@ template <int LK>
 __device__ __forceinline__ void wg_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int tid,
                                              uint64_t* __restrict__ lds, uint64_t* __restrict__ keys_out,
                                              int32_t* __restrict__ flatten_ids, int64_t* __restrict__ isect_ids,
-                                             int64_t cam_enc) {
+                                             int64_t cam_enc, const int32_t* __restrict__ storage_of = nullptr) {
   constexpr int KPT = 1 << LK, RUN = 64 * KPT;
   const int lane = tid & 63, wv = tid >> 6;
   uint64_t k[KPT];
@@ -134,7 +134,7 @@ __device__ __forceinline__ void wg_sort_tile(const uint64_t* __restrict__ src, i
         if (ib >= 2 * RUN || (ia < 2 * RUN && A[ia] <= B[ib])) v = A[ia++];
         else v = B[ib++];
         if (d0 + q < n) {
-          flatten_ids[s + d0 + q] = (int32_t)(uint32_t)v;
+          flatten_ids[s + d0 + q] = list_id(storage_of, v);
           if (isect_ids) isect_ids[s + d0 + q] = cam_enc | ((int64_t)t << 32) | (int64_t)(v >> 32);
           if (keys_out) keys_out[s + d0 + q] = v;
         }

@@ -61,7 +61,7 @@ class _FusedRasterization(torch.autograd.Function):
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rgb else None, sh_degree, K_sh,
             ptr(viewmat), ptr(K), N, W, H, eps2d, near, far, radius_clip, int(antialiased), tw, th, ty0, ty1,
             ptr(radii), ptr(Q0), ptr(Q1), ptr(Q2), ptr(comps), ptr(tpg), ptr(offs), ptr(n_is), ptr(ws), ws_bytes,
-            None, None, 0, None, st), "gsl_fused_project")  # two-pass binning: tile sizes are not known in advance
+            None, None, 0, None, None, st), "gsl_fused_project")  # two-pass binning: tile sizes are not known in advance
         n_isects = int(n_is.item())  # output sizes depend on it (gsplat syncs at the same point)
         cap = max(n_isects, 1)
         keys = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -70,7 +70,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_bin(ptr(Q0), ptr(radii), N, tw, th, ty0, ty1, tile_n_bits(n_tiles), ptr(offs), n_isects,
                                 ptr(keys), ptr(flatten_ids) if n_isects else None,
                                 ptr(isect_ids) if (want_isect_ids and n_isects) else None, ptr(ws), ws_bytes, 0, None, 0,
-                                None, None, 0, st), "gsl_fused_bin")
+                                None, None, 0, None, None, st), "gsl_fused_bin")
         render = torch.zeros(H, W, D, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, D, dtype=f32, device=dev)
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
@@ -81,7 +81,7 @@ class _FusedRasterization(torch.autograd.Function):
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
                                        ptr(last_ids), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, None, 0, None, None,
-                                       st),
+                                       None, st),
               "gsl_fused_raster_fwd")
         ctx.save_for_backward(means, quats, scales, opacities, colors if rgb else torch.empty(0, device=dev),
                               viewmat, K, radii, Q0, Q1, Q2 if rgb else torch.empty(0, device=dev),
@@ -136,7 +136,8 @@ class _FusedRasterization(torch.autograd.Function):
             ptr(means), ptr(quats), ptr(scales), ptr(opacities), ptr(colors) if rgb else None, sh_degree, ctx.K_sh,
             ptr(viewmat), ptr(K), N, W, H, eps2d, int(antialiased), D, ptr(radii), ptr(Q1),
             ptr(comps) if antialiased else None, ptr(vacc), ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opac),
-            ptr(v_colors), ptr(v_viewmat), ptr(ws), ws_bytes, n_tiles, None, None, None, None, 0, 0, 0, 0, 0, None, None, 1, st),
+            ptr(v_colors), ptr(v_viewmat), ptr(ws), ws_bytes, n_tiles, None, None, None, None, 0, 0, 0, 0, 0, None, None, 1, None,
+            st),
             "gsl_fused_project_bwd")
         return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
                 v_opac if ni[3] else None, v_colors if (ni[4] and rgb) else None, v_viewmat, None, None, None)
@@ -208,8 +209,12 @@ class _CachedRasterization(torch.autograd.Function):
         rc.render, rc.alphas, rc.last_ids = render, alphas, last_ids
         if rc.generation != ctx.gen:
             # another forward has used this context since: its records and lists are not this node's any more --
-            # run this node's forward again (same inputs: same outputs, rewritten into the saved tensors)
-            rc.forward(*inputs)
+            # run this node's forward again (same inputs: same outputs, rewritten into the saved tensors).  The buffers
+            # may have been re-sized for the later call's scene: check, and refuse to build a gradient from truncated lists
+            why = rc.forward_checked(*inputs)
+            if why is not None:
+                raise RuntimeError(f"backward of a stale rasterization node: {why} (a later call with the same signature "
+                                   "re-sized the cached context; set GSLOC_DROPIN_CACHE=0 to give every call its own buffers)")
         rc._inputs = inputs
         ni = ctx.needs_input_grad
         full = any(ni[:5])
@@ -249,7 +254,8 @@ def cached_rasterization(means, quats, scales, opacities, colors, viewmat, K, wi
            float(radius_clip), bool(antialiased), means.device.index)
     rc = _cached_context(key, lambda: RenderContext(
         N, width, height, render_mode, sh_degree=sh_degree, K_sh=K_sh, device=means.device, eps2d=eps2d,
-        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, antialiased=antialiased, full_grads=False))
+        near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, antialiased=antialiased, full_grads=False,
+        reorder=False))  # (the drop-in call returns per-Gaussian meta tensors and lists in the caller's order)
     tensors = (means, quats, scales, opacities, colors, viewmat)
     # hit lists only when somebody can back-propagate through this call (geometry.py:117-132 renders under no_grad)
     rc.record_hits = torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)

@@ -199,6 +199,16 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     leaves them so.  A projection that follows another one without a compositing forward in
  *                     between (skipped, or failed) finds the state word in ws dirty and raises flags[3] = 1: zero-fill
  *                     ws and run the iteration again.
+ * Tile-order placement (order_ids / storage_of, int32[N] each, may be NULL together everywhere): a caller that renders the
+ *                     same Gaussians many times (a tracker: /root/reference/src/my_gsplat/model.py:137-175 builds them
+ *                     once per frame) may STORE them sorted by the tile of their centre, so that the record gathers of a
+ *                     tile's list touch a few contiguous runs.  The list order must not depend on the placement -- depth
+ *                     ties break by Gaussian index -- so gsl_fused_project (and gsl_fused_bin's scatter pass) put
+ *                     order_ids[slot], the Gaussian's ORIGINAL index, into the low key word, and every sort
+ *                     (gsl_fused_bin, gsl_long_sort, the sorting gsl_fused_raster_fwd) writes storage_of[original] into
+ *                     flatten_ids: the lists are the unpermuted run's lists with every id relabelled, images and
+ *                     last_ids bit-identical.  Everything per Gaussian (records, vacc, v_means ...) is then in storage
+ *                     order.  Not with write_sorted_keys (the deterministic backward searches the keys by id).
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
  *                     v_viewmat[16] is overwritten (row 3 = 0).  tiny_trec / tiny_vcT (may be NULL): the slabs
@@ -216,18 +226,20 @@ int gsl_fused_project(const float* means, const float* quats, const float* scale
                       int antialiased, int tile_w, int tile_h, int ty0, int ty1, int32_t* radii,
                       float* Q0, float* Q1, float* Q2, float* compensations,
                       int32_t* tiles_per_gauss, int32_t* tile_offsets, int32_t* n_isects, void* ws,
-                      size_t ws_bytes, void* Qh, void* bins, int bin_cap, int32_t* flags, void* stream);
+                      size_t ws_bytes, void* Qh, void* bins, int bin_cap, int32_t* flags,
+                      const int32_t* order_ids, void* stream);
 int gsl_fused_bin(const float* Q0, const int32_t* radii, int N, int tile_w, int tile_h, int ty0,
                   int ty1, int tile_n_bits, int32_t* tile_offsets, int64_t capacity,
                   uint64_t* sort_keys, int32_t* flatten_ids, int64_t* isect_ids, void* ws,
                   size_t ws_bytes, int write_sorted_keys, void* bins, int bin_cap, int32_t* n_isects,
-                  int32_t* flags, int long_min, void* stream);
+                  int32_t* flags, int long_min, const int32_t* order_ids, const int32_t* storage_of, void* stream);
 int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed,
                          int width, int height, int tile_w, int tile_h, int ty0, int ty1,
                          const int32_t* tile_offsets, const int32_t* flatten_ids, int64_t capacity,
                          float* render, float* alphas, int32_t* last_ids, int row0, int row1, const void* Qh,
                          void* binned_ws, uint32_t* isect_hits, int32_t* isect_hit_counts, int long_min,
-                         void* sort_bins, int bin_cap, int32_t* n_isects, int32_t* flags, void* stream);
+                         void* sort_bins, int bin_cap, int32_t* n_isects, int32_t* flags,
+                         const int32_t* storage_of, void* stream);
 /* sort_bins != NULL (binned projection, whole frame, bin_cap <= 2048, long_min == 0): every workgroup first does
  * gsl_fused_bin's work for its own tile -- adds up the sizes of the tiles before it, sorts its bin in LDS, writes
  * tile_offsets / flatten_ids (outputs then, despite the const) / n_isects and raises flags like gsl_fused_bin -- and
@@ -260,7 +272,8 @@ int gsl_long_sort_segment(void); /* keys per sorted run of gsl_long_sort before 
  * bin; flatten_ids receives the result.  One workgroup used to take 1.6 ms for a 23 k-entry list. */
 int gsl_long_sort(const int32_t* tile_offsets, int tile_w, int tile_h, int ty0, int ty1, int64_t capacity,
                   uint64_t* bins, int bin_cap, uint64_t* sort_keys, int32_t* flatten_ids, int long_min,
-                  void* long_ws, size_t long_ws_bytes, int max_seg, int passes, void* stream);
+                  void* long_ws, size_t long_ws_bytes, int max_seg, int passes, const int32_t* storage_of,
+                  void* stream);
 int gsl_long_raster_fwd(const float* Q0, const float* Q1, const float* Q2, int channels, int ed, int width,
                         int height, int tile_w, int tile_h, int ty0, int ty1, const int32_t* tile_offsets,
                         const int32_t* flatten_ids, int64_t capacity, float* render, float* alphas,
@@ -283,7 +296,13 @@ int gsl_fused_project_bwd(const float* means, const float* quats, const float* s
                           float* v_viewmat, void* ws, size_t ws_bytes, int n_tiles, const float* vrow,
                           const uint64_t* sorted_keys, const int32_t* tile_offsets, const float* Q0, int tile_w,
                           int tile_h, int ty0, int ty1, int64_t capacity, float* tiny_trec, const float* tiny_vcT,
-                          int reduce_viewmat, void* stream);
+                          int reduce_viewmat, int32_t* v_colors_state, void* stream);
+/* v_colors_state (int32[1], may be NULL): the caller's promise that v_colors is the SAME buffer in every call that is
+ * given this state word; initialise it to 1 together with a zero-filled v_colors (or to 0 for a buffer of unknown
+ * content).  While it reads 1 a Gaussian whose colour gradient is zero -- all of them under a depth-only loss,
+ * /root/reference/src/my_gsplat/gs_trainer_total.py:111-123 -- skips its zero stores (48 of the ~92 bytes per Gaussian the
+ * call writes at SH degree 1); a launch that writes a real colour gradient marks the buffer dirty and the following
+ * launch stores everything again.  Maintained by the reduction kernel (reduce_viewmat = 1). */
 const float* gsl_fused_viewmat_rows(const void* ws, int n_tiles);
 
 /* "Tiny splat" backward: valid when every r_cull (Q1[:,3]) is < 2 px, i.e. no splat reaches more than 4x4

@@ -73,6 +73,11 @@ class FakeContext:
     def _project(self, *a):
         pass
 
+    order_ids = storage_of = None
+
+    def _place(self, *a):
+        return a
+
     _bin = _raster_fwd = _project
     _raster_bwd = _project_bwd = _project
 
