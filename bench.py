@@ -50,7 +50,12 @@ WORKLOADS = {
     # as-coded kNN^2 scales (sigma_px -> 0): ref/src/data/Image.py:29,35, my_gsplat/geometry.py:60-64, cam_params.json:3-4
     "D": dict(n=816_000, width=1200, height=680, kind="depth_frame", stride=1, holes=False),
 }
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_traffic.json")   # FETCH_SIZE / WRITE_SIZE / SQ counters (scripts/pmc_summary.py)
+ISSUE_MODEL = os.path.join("profiles", "r04_issue_model.json")   # static VALU class mix of the hot loops (scripts/issue_model.py)
+# measured issue cost of one wave-instruction on one SIMD, ns (profiles/r04_valu_issue.txt): 2-cycle class (fma / add / mul
+# / mov / logic on VGPRs), 4-cycle class (anything with an SGPR operand, v_cndmask, v_cmp, DPP, min / max, packed f32,
+# integer bit ops), transcendentals
+ISSUE_NS = {"fast": 1.04, "slow": 1.80, "trans": 3.40}
 
 
 def parse():
@@ -182,6 +187,59 @@ def pmc_traffic(stage):
     return sum(tot) if tot else None
 
 
+def pmc_kernels():
+    """Per-kernel counter summary of PMC_SUMMARY while its kernel-source hash matches this build, else None."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path):
+        return None
+    summary = json.load(open(path))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        from pmc_summary import csrc_sha
+        if summary.get("csrc_sha") != csrc_sha():
+            return None
+    except Exception:  # noqa: BLE001
+        return None
+    return summary["kernels"]
+
+
+def issue_bound(stage, launch_ms):
+    """The bound the compositing kernels actually run against: VALU issue.  Instructions per launch
+    from the hash-matched SQ-counter summary; priced per class with the measured issue costs (ISSUE_NS) at the static
+    class mix of the kernel's hot loop (scripts/issue_model.py), next to the all-fast and all-slow prices."""
+    ks = pmc_kernels()
+    if not ks:
+        return None
+    names = [k for k in ks if any(k.startswith(p) for p in STAGE_KERNELS.get(stage, ())) and "sq" in ks[k]]
+    if not names:
+        return None
+    k = max(names, key=lambda n: ks[n]["sq"].get("SQ_INSTS_VALU", 0))
+    sq = ks[k]["sq"]
+    valu = sq.get("SQ_INSTS_VALU")
+    mix = None
+    try:
+        model = json.load(open(os.path.join(ROOT, ISSUE_MODEL)))
+        from pmc_summary import csrc_sha
+        if model.get("csrc_sha") == csrc_sha():
+            mix = next((v for n, v in model["kernels"].items() if k.startswith(n)), None)
+    except Exception:  # noqa: BLE001
+        mix = None
+    simds = 1024.0
+    out = {"kernel": k, "valu_insts": valu, "salu_insts": sq.get("SQ_INSTS_SALU"), "lds_insts": sq.get("SQ_INSTS_LDS"),
+           "lds_array_busy_frac": (sq["SQ_LDS_IDX_ACTIVE"] / 256.0) / sq["SQ_BUSY_CYCLES_per_se"]
+           if sq.get("SQ_LDS_IDX_ACTIVE") and sq.get("SQ_BUSY_CYCLES_per_se") else None,
+           "issue_us_if_all_2_cycle": valu * ISSUE_NS["fast"] / simds * 1e-3 if valu else None,
+           "issue_us_if_all_4_cycle": valu * ISSUE_NS["slow"] / simds * 1e-3 if valu else None,
+           "issue_ns_per_class": ISSUE_NS, "source": f"{PMC_SUMMARY} + {ISSUE_MODEL} (both hash-matched to this build)"}
+    if valu and mix:
+        tot = float(mix["fast"] + mix["slow"] + mix["trans"])
+        ns = (mix["fast"] * ISSUE_NS["fast"] + mix["slow"] * ISSUE_NS["slow"] + mix["trans"] * ISSUE_NS["trans"]) / tot
+        out["hot_loop_class_mix"] = {c: mix[c] / tot for c in ("fast", "slow", "trans")}
+        out["issue_peak_us"] = valu * ns / simds * 1e-3
+        out["frac"] = out["issue_peak_us"] / (launch_ms * 1e3) if launch_ms else None
+    return out
+
+
 def build_scene(args, dev):
     """The synthetic input of the workload (seeded) and the camera it is rendered from."""
     from gsplatloc_amd.synthetic import perturbed_pose, random_scene
@@ -246,26 +304,29 @@ def cpu_baseline(args, scene, gpu):
         # timed step's): HIP against the float64 oracle (max over the seeds), HIP against the oracle's own float32 build
         # (like for like) and that build against float64 (the float32 floor of this configuration).  The bound applied is
         # the tests' (tests/parity.py): 1e-4, or min(2 x floor, 8e-4) where the floor itself is above 5e-5.
-        worst = vs32 = floor32 = 0.0
+        from gsplatloc_amd.synthetic import depth_upstream
+        worst = vs32 = floor32 = det = 0.0
         for seed in (1, 2, 3):
-            if seed == 1:
-                vk = v
-            else:
-                gk = torch.Generator().manual_seed(seed)
-                vk = np.zeros_like(v)
-                vk[..., 3] = torch.randn(h, w, generator=gk).numpy()
+            vk = v if seed == 1 else depth_upstream(h, w, seed).numpy()  # (the tests' generator, dtype and seeds)
             vm = vk * ok[..., None]
             want, want32 = step("f64", vm), step("f32", vm)
             got = gpu["backward"](torch.from_numpy(vm))
             gv = got.cpu().double().numpy()[:3]
+            if gpu.get("backward_deterministic") is not None:  # the same sums in a fixed order (no float atomics)
+                gd = gpu["backward_deterministic"](torch.from_numpy(vm)).cpu().double().numpy()[:3]
+                det = max(det, float(np.abs(gd - want["v_viewmat"][:3]).max() / np.abs(want["v_viewmat"][:3]).max()))
             w64, w32 = want["v_viewmat"][:3], want32["v_viewmat"][:3].astype(np.float64)
             worst = max(worst, float(np.abs(gv - w64).max() / np.abs(w64).max()))
             vs32 = max(vs32, float(np.abs(gv - w32).max() / np.abs(w32).max()))
             floor32 = max(floor32, float(np.abs(w32 - w64).max() / np.abs(w64).max()))
-        bound = max(1e-4, min(2.0 * floor32, 8e-4)) if args.staging == "fp32" else None
+        from tests.parity import POSE_GRAD_CAPS, pose_grad_bound
+        kind = "X" if n > 1_100_000 else ("sigma1" if (args.kind == "random" and args.sigma_px >= 0.5) else "subpixel")
+        bound = pose_grad_bound(floor32, kind) if args.staging == "fp32" else None
         parity = {"against": "oracle/csrc/gsplat_oracle.c float64",
                   "tolerance": ("images: 1e-4 relative + 2e-5 absolute (north_star's 1e-4); pose gradient: "
-                                f"{bound:.1e} = max(1e-4, min(2 x float32 floor, 8e-4)) of its largest entry, flip-aware")
+                                f"{bound:.1e} of its largest entry (tests/parity.py POSE_GRAD_CAPS[{kind!r}]: a fixed cap per kind of "
+                                "configuration, set from the measured table), flip-aware; north_star's 1e-4 is met by the "
+                                "images and by small scenes, NOT by the whole-frame pose gradient at this size")
                                if args.staging == "fp32" else
                                "fp16-staged records: ~1e-3 relative expected (half has 11 significant bits)",
                   "depth_rel_err": {"mean": float(d_rel.mean()), "p99": float(np.quantile(d_rel.reshape(-1)[::7], 0.99)),
@@ -275,6 +336,8 @@ def cpu_baseline(args, scene, gpu):
                   "pixels_beyond_tolerance": float(1.0 - ok.mean()),
                   "v_viewmat_rel_err": worst, "v_viewmat_seeds": 3,
                   "v_viewmat_vs_f32_oracle": vs32, "v_viewmat_f32_oracle_vs_f64": floor32,
+                  "v_viewmat_deterministic_rel_err": det if gpu.get("backward_deterministic") is not None else None,
+                  "v_viewmat_meets_north_star_1e-4": worst < 1e-4,
                   "v_viewmat_within_bound": (worst < bound) if bound is not None else None,
                   "v_viewmat_note": "max over 3 white-noise upstream gradients (a sum of ~1e6 terms of random sign); the "
                                     "oracle's float32 build differs from its float64 build by v_viewmat_f32_oracle_vs_f64",
@@ -316,8 +379,16 @@ def backward_name(ctx):
     if getattr(ctx, "tiny", False):
         return "tiny-splat slabs, folded inside the projection backward"
     if getattr(ctx, "deterministic", False):
-        return "quadrant walk + MFMA pixel sums (deterministic)"
-    return "16-lane groups: each DPP row walks its 4x4 block's list (pairs from the forward's hit masks)"
+        return "quadrant walk, per-splat pixel sums by v_mfma_f32_16x16x4_f32, one gradient row per intersection (deterministic)"
+    return ("one wave per 8x8 quadrant, each 16-lane DPP row walks its 4x4 block's entries of the quadrant's hit LIST "
+            "(written by the forward), DPP reduce-scatter, packed 64-byte atomics")
+
+
+def placement_name(ctx):
+    if getattr(ctx, "order_ids", None) is not None:
+        return ("tile order: the context stores its own copies of the Gaussians sorted by the tile of the projected centre "
+                "(once per frame, at calibrate(); the sort key keeps the caller's index, lists bit-identical up to relabelling)")
+    return "as given by the caller"
 
 
 def event_stats(ms):
@@ -329,7 +400,7 @@ def event_stats(ms):
     return {"median": q(0.5), "p10": q(0.1), "p90": q(0.9), "n": len(s)}
 
 
-def variant_rate(dev, N, W, H, sigma_px, order, steps=100, warmup=5, depth_frame=False):
+def variant_rate(dev, N, W, H, sigma_px, order, steps=100, warmup=5, depth_frame=False, reorder=None):
     """Side measurement: the same step on another variant of the workload (graph replay, all gradients).  Per-step HIP
     events, median over `steps` replays (a wall-clock mean over a handful of replays cannot tell one host stall from a
     slow kernel); the wall-clock mean is reported next to it.  depth_frame: workload D (one Gaussian per pixel of a
@@ -338,19 +409,17 @@ def variant_rate(dev, N, W, H, sigma_px, order, steps=100, warmup=5, depth_frame
     from gsplatloc_amd.synthetic import depth_frame_scene, perturbed_pose, random_scene
 
     if depth_frame:
-        sc = depth_frame_scene(W, H, stride=1, holes=False, device=dev)
+        sc = depth_frame_scene(W, H, stride=3 if depth_frame == "S" else 1, holes=False, device=dev)
         viewmat, N = sc["viewmat"], sc["N"]
     else:
         sc = random_scene(N, W, H, sigma_px=sigma_px, device=dev, order=order)
         viewmat = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
     K = sc["K"].contiguous()
-    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True)
+    ctx = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=True, reorder=reorder)
     inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
     n_is = ctx.calibrate(*inp)
-    g = torch.Generator().manual_seed(1)
-    v = torch.zeros(H, W, 4)
-    v[..., 3] = torch.randn(H, W, generator=g)
-    v = v.to(dev)
+    from gsplatloc_amd.synthetic import depth_upstream
+    v = depth_upstream(H, W, 1).to(dev)
     va = torch.zeros(H, W, 1, device=dev)
 
     def step():
@@ -387,7 +456,93 @@ def variant_rate(dev, N, W, H, sigma_px, order, steps=100, warmup=5, depth_frame
             "intersections_per_gaussian": n_is / N, "ms_per_step": ev["median"],
             "step_ms_hip_events": ev, "ms_per_step_wall_mean": wall * 1e3, "warmup_ms_per_step_wall_mean": warm_wall * 1e3,
             "gaussians_per_s": N / dt,
-            "backward": backward_name(ctx)}
+            "backward": backward_name(ctx), "placement": placement_name(ctx)}
+
+
+def api_rate(dev, context_R_ms=None):
+    """The drop-in boundary, timed as the reference uses it (/root/reference/src/my_gsplat/model.py:195-213 inside the loop
+    of gs_trainer_total.py:79-267): wall time per  `from gsplat import rasterization`  call with the reference's keyword
+    arguments + `.backward()` from the depth channel, allocation of the outputs and the status read-back included, pose
+    gradient only (what the tracker consumes) and with the per-Gaussian gradients the reference's parameters would also
+    receive; best of three windows after a warm-up; at S (102 400 Gaussians of a 640x480 depth frame) and R.  Beside it
+    the same step on a RenderContext as one HIP graph."""
+    from gsplat import rasterization
+    from gsplatloc_amd.fused import clear_context_cache
+    from gsplatloc_amd.synthetic import depth_frame_scene, perturbed_pose, random_scene
+
+    def api(sc, c2w, W, H, full, n):
+        def step():
+            c2w_g = c2w.clone().requires_grad_()
+            m = sc["means"].clone().requires_grad_(full)
+            render_colors, render_alphas, info = rasterization(
+                means=m, quats=sc["quats"], scales=sc["scales"], opacities=sc["opacities"], colors=sc["sh"], sh_degree=1,
+                viewmats=torch.linalg.inv(c2w_g)[None], Ks=sc["K"][None], width=W, height=H, packed=False, absgrad=False,
+                sparse_grad=False, far_plane=1e10, near_plane=1e-2, render_mode="RGB+ED", rasterize_mode="classic")
+            assert render_colors.shape[-1] == 4
+            (render_colors[..., 3:4] * 0.5).sum().backward()
+        for _ in range(30):
+            step()
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t) / n * 1e3)
+        return best
+
+    out = {"call": "gsplat.rasterization(**kw of ref model.py:195-213) + backward from the depth channel, wall ms per call"}
+    for name in ("S", "R"):
+        if name == "S":
+            W, H = 640, 480
+            sc = depth_frame_scene(W, H, stride=3, device=dev)
+            c2w = torch.linalg.inv(sc["viewmat"])
+        else:
+            W, H = 1200, 680
+            sc = random_scene(1_000_000, W, H, device=dev)
+            c2w = perturbed_pose().to(dev)
+        sc = dict(sc, K=sc["K"].contiguous())
+        n = 300 if name == "S" else 100
+        api(sc, c2w, W, H, False, 30)  # (first use: context creation and calibration)
+        out[name] = {"pose_gradient_only_ms": api(sc, c2w, W, H, False, n),
+                     "with_gaussian_gradients_ms": api(sc, c2w, W, H, True, n)}
+        if name == "S":
+            v = variant_rate(dev, sc["means"].shape[0], W, H, 0.0, "raster", steps=100, depth_frame="S")
+            out[name]["render_context_graph_ms"] = v["ms_per_step"]
+        elif context_R_ms is not None:
+            out[name]["render_context_graph_ms"] = context_R_ms
+        clear_context_cache()
+    return out
+
+
+def frame_rate(dev, n_frames=9):
+    """Per-frame end-to-end rate of the reference's evaluation protocol (python -m gsplatloc_amd.eval: GT-initialised,
+    <= 2000 iterations, early stop; /root/reference/src/my_gsplat/gs_trainer_total.py:45-282, dataset.py:345-383) on a synthetic
+    Replica-format 640x480 sequence written to a temporary directory, with the wall time of each phase of a frame."""
+    import pathlib
+    import shutil
+    import tempfile
+
+    from gsplatloc_amd.data.dataset import Parser
+    from gsplatloc_amd.eval import evaluate_room
+    from gsplatloc_amd.synthetic import write_replica_sequence
+
+    root = pathlib.Path(tempfile.mkdtemp())
+    try:
+        write_replica_sequence(root, 640, 480, n_frames + 1)
+        parser = Parser("Replica", "room0", normalize=True, input_folder=str(root))
+        evaluate_room(parser, num_iters=2000, max_frames=2, verbose=False)  # warm-up: library, allocator, first captures
+        res = evaluate_room(parser, num_iters=2000, max_frames=None, verbose=False, profile=True)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    ph = res.get("phase_seconds") or {}
+    tot = sum(ph.values()) or 1.0
+    return {"protocol": "gsplatloc_amd.eval.evaluate_room, synthetic Replica-format sequence 640x480, normalize=True",
+            "frames": res["frames"], "frames_per_s": res["frames_per_s"], "mean_iterations_per_frame": res["mean_steps"],
+            "ATE_m": res["ATE"], "AAE_deg": res["AAE"],
+            "phase_ms_per_frame": {k: v / res["frames"] * 1e3 for k, v in ph.items()},
+            "setup_fraction_of_frame": 1.0 - ph.get("optimise", 0.0) / tot}
 
 
 def pose_opt_rate(dev):
@@ -482,6 +637,14 @@ def main():
         cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
         rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank]
         idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
+        # the guard band is checked, not assumed (GraphTracker does the same at every poll, where the pose
+        # moves): no Gaussian outside the kept set may reach the strip at the pose the timed steps render
+        kept = torch.zeros(N, dtype=torch.bool, device=dev)
+        kept[idx] = True
+        reach = torch.zeros(N, dtype=torch.bool, device=dev)
+        reach[gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows, guard_tiles=0)] = True
+        band_violations = int((reach & ~kept).sum())
+        assert band_violations == 0, f"{band_violations} Gaussians outside the kept set reach strip {rows}"
         for k in sc:
             sc[k] = sc[k][idx].contiguous()
         n_local = int(idx.numel())
@@ -491,10 +654,8 @@ def main():
                           staging=args.staging)
     n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
     trace(f"calibrated, {n_isects} intersections")
-    g = torch.Generator().manual_seed(1)
-    v_render = torch.zeros(H, W, 4)
-    v_render[..., 3] = torch.randn(H, W, generator=g)
-    v_render = v_render.to(dev)
+    from gsplatloc_amd.synthetic import depth_upstream
+    v_render = depth_upstream(H, W, 1).to(dev)  # (seed 1 of the parity statement's three: tests/test_gpu_configs.py)
     v_alphas = torch.zeros(H, W, 1, device=dev)
     pose_grad = torch.zeros(16, device=dev)  # this rank's 16 floats of the all-reduce
     host16 = None
@@ -625,10 +786,13 @@ def main():
                 "intersections_per_gaussian": (n_total / N) if world == 1 else None,
                 "strip_intersections_rank0": n_total, "tile_rows_rank0": list(rows), "gaussians_rank0": n_local,
                 "parallelism": "single GPU" if world == 1 else f"{world} screen-tile strips + 1 all-reduce(16 f32)",
+                "guard_band": None if world == 1 else "Gaussians pruned per strip with a 1-tile guard band; checked at the "
+                                                      "rendered pose: 0 Gaussians outside the kept set reach the strip",
                 "launch": ("hipGraph replay" + (", all-reduce captured in the graph" if collective_in_graph else
                                                  (", eager all-reduce after the replay" if dist is not None else "")))
                           if graph is not None else "eager",
                 "backward": backward_name(ctx),
+                "gaussian_placement": placement_name(ctx),
                 "binning": ("keys written into per-tile bins by the projection kernel (sizes from calibrate()), "
                             "register sort per tile" if getattr(ctx, "bins", None) is not None
                             else "count, scan, scatter, register sort per tile"),
@@ -641,13 +805,34 @@ def main():
                 "traffic_source": f"rocprofv3 --pmc summary {PMC_SUMMARY} of this command, quoted only while its kernel-source "
                                   "hash matches this build (counters cannot be read from inside the process)",
                 "algorithmic_bytes_per_launch": bytes_stage[dom], "avg_launch_ms": dom_ms,
-                "whole_step": {"model": "SURVEY.md 8(d)", "algorithmic_bytes": sum(bytes_stage.values()),
-                               "achieved_GBps": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9,
-                               "frac": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9 / 8000.0},
-                "whole_step_implementation_bytes": {
-                    "note": "bin stage counted as what this build moves (keys written once, sorted in LDS, ids written)",
-                    "algorithmic_bytes": sum(impl_bytes.values()),
-                    "frac": sum(impl_bytes.values()) / (ms * 1e-3) / 1e9 / 8000.0},
+                # per stage: the SURVEY.md 8(d) bytes AND what this build moves; a stage whose model bytes would need more
+                # than the chip's peak in the time measured is flagged -- the kernel is not doing the model's work (the bin
+                # stage: the model prices six radix passes, the build sorts in registers), and its `frac` is the
+                # implementation figure
+                "stages": {
+                    s_: {"ms": stage_ms[s_], "model_bytes": bytes_stage[s_], "implementation_bytes": impl_bytes[s_],
+                         "model_frac": bytes_stage[s_] / (stage_ms[s_] * 1e-3) / 8e12,
+                         "frac": impl_bytes[s_] / (stage_ms[s_] * 1e-3) / 8e12,
+                         **({"flag": "model bytes / time exceeds the HBM peak: the kernel does not move the model's bytes; "
+                                     "frac counts what it moves"}
+                            if bytes_stage[s_] / (stage_ms[s_] * 1e-3) / 8e12 > 1.0 else {})}
+                    for s_ in stage_ms if stage_ms.get(s_)},
+                "whole_step": {"model": "SURVEY.md 8(d) bytes, the bin stage counted as what this build moves (keys written "
+                                        "once by the projection, sorted in registers, ids written): no credit for radix "
+                                        "passes it does not run",
+                               "algorithmic_bytes": sum(impl_bytes.values()),
+                               "achieved_GBps": sum(impl_bytes.values()) / (ms * 1e-3) / 1e9,
+                               "frac": sum(impl_bytes.values()) / (ms * 1e-3) / 1e9 / 8000.0},
+                "whole_step_survey_model": {
+                    "note": "SURVEY.md 8(d) as written, six radix passes in the bin stage included; quoted for continuity "
+                            "with rounds 1-3, not a statement about this build's traffic",
+                    "algorithmic_bytes": sum(bytes_stage.values()),
+                    "frac": sum(bytes_stage.values()) / (ms * 1e-3) / 1e9 / 8000.0},
+                # what the compositing kernels are actually bound by
+                "issue": issue_bound(dom, dom_ms) if (world == 1 and headline and N == 1_000_000) else None,
+                "issue_other_compositing_stage": issue_bound("raster_fwd" if dom == "raster_bwd" else "raster_bwd",
+                                                             stage_ms.get("raster_fwd" if dom == "raster_bwd" else "raster_bwd"))
+                if (world == 1 and headline and N == 1_000_000) else None,
                 "stage_ms": stage_ms,
             },
         }
@@ -658,11 +843,27 @@ def main():
                 torch.cuda.synchronize()
                 return grads["viewmat"].clone()
 
+            det_ctx = []
+
+            def gpu_backward_det(vm):  # same sums, fixed order (deterministic=True): built on first use, fp32 records only
+                if not det_ctx:
+                    dc = C.RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False,
+                                         deterministic=True, reorder=False)
+                    dc.calibrate(*args_in)
+                    det_ctx.append(dc)
+                dc = det_ctx[0]
+                dc.forward(*args_in)
+                grads = dc.backward(vm.float().to(dev).contiguous(), v_alphas, full=False)
+                torch.cuda.synchronize()
+                return grads["viewmat"].clone()
+
             def baseline_and_parity():
                 ctx.forward(*args_in)
                 torch.cuda.synchronize()
                 gpu = {"render": getattr(ctx, "render", None), "alphas": getattr(ctx, "alphas", None),
-                       "v_render": v_render, "backward": gpu_backward, "n_isects": n_total}
+                       "v_render": v_render, "backward": gpu_backward, "n_isects": n_total,
+                       "backward_deterministic": gpu_backward_det if (args.staging == "fp32" and N <= 1_100_000
+                                                                      and hasattr(ctx, "render")) else None}
                 if gpu["render"] is not None:
                     gpu["render"], gpu["alphas"] = gpu["render"].clone(), gpu["alphas"].clone()
                 return cpu_baseline(args, dict(scene, K=K), gpu)
@@ -676,11 +877,16 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not args.no_tracker:
             out["pose_opt"] = guarded(pose_opt_rate, dev)
+            # the drop-in boundary and the per-frame end-to-end figure
+            out["api"] = guarded(api_rate, dev, ms if (headline and N == 1_000_000) else None)
+            out["frame"] = guarded(frame_rate, dev)
         if world == 1 and not args.no_variants:
             # same N and image, the other synthetic inputs of SURVEY.md 8(d): sigma_px -> 0 is the regime of the
             # reference's as-coded kNN scales; "raster" is the Gaussian order of a back-projected depth frame
             out["variants"] = [guarded(variant_rate, dev, args.n, W, H, s_, o_) for s_, o_ in
                                ((1.0, "raster"), (0.0, "random"), (0.0, "raster"))]
+            # the headline input WITHOUT the tile-order placement (Gaussians gathered where the caller put them)
+            out["variants"].append(guarded(variant_rate, dev, args.n, W, H, 1.0, "random", reorder=False))
             out["variants"].append(guarded(variant_rate, dev, W * H, W, H, 0.0, "raster", depth_frame=True))
         th1 = throttle_stats()
         try:  # BENCH_r02 recorded one process still alive when the command returned: name whatever this process started

@@ -168,16 +168,15 @@ class RenderContext:
         sorted (stably) by the tile of the projected centre at the calibration pose; `order_ids[slot]` is the original
         index and stays the low word of the sort key, so depth ties break exactly as in the caller's order -- the lists
         are the unpermuted run's lists with every id relabelled (`storage_of`), images and last_ids bit-identical
-        (tests/test_gpu_reorder.py).  Everything per Gaussian the context owns (records, radii, gradient buffers) is then
-        in STORAGE order: use grads_in_input_order() / order_ids."""
+        (tests/test_gpu_reorder.py).  Everything per Gaussian the context owns (records, radii, tiles_per_gauss, gradient
+        buffers) is then in STORAGE order: use grads_in_input_order() / order_ids."""
         want = self.reorder
         if want is None:
             want = (os.environ.get("GSLOC_REORDER", "1") != "0" and self.N >= self.REORDER_MIN_N
-                    and not self._screen_coherent_order())
+                    and not self.deterministic and not self._screen_coherent_order())
         if not want or self.N < 2:
             return False
         assert not self.deterministic, "deterministic mode finds a Gaussian's rows by key: no tile-order placement"
-        assert self.tiles_per_gauss is None, "tiles_per_gauss is a per-Gaussian output in caller order: reorder=False"
         vis = self.Q1[:, 3] > 0
         tx = torch.clamp(torch.floor(self.Q0[:, 0] / 16.0), 0, self.tw - 1).to(torch.int64)
         ty = torch.clamp(torch.floor(self.Q0[:, 1] / 16.0), 0, self.th - 1).to(torch.int64)

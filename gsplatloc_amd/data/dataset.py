@@ -211,6 +211,13 @@ class AlignData:
     tar_nums: int
 
 
+def _now(device) -> float:
+    import time
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    return time.perf_counter()
+
+
 class Parser:
     """dataset.py:333-383: frame pair (i, i+1) -> tracker inputs.  Both clouds are placed with the TARGET
     pose (dataset.py:349-350); with normalize=True the pair is moved to the target cloud's PCA frame and
@@ -222,31 +229,63 @@ class Parser:
         self.device = torch.device(device)
         self.K = torch.as_tensor(self._data.K, dtype=torch.float32, device=self.device)
         self.normalize = normalize
+        self.phase_seconds = None  # dict: per-phase wall time of __getitem__ (set by a profiling caller; costs two syncs)
+        # Frame i + 1 of pair i is frame i of pair i + 1: keep the last two frames' device tensors, and decode the frame
+        # the NEXT pair will need on a host thread while the tracker optimises this one (PNG / JPEG decoding releases the
+        # GIL; reading was 14 of a frame's 85 ms at 640x480 -- the largest item outside the optimisation loop)
+        self._frames = {}
+        self._pending = {}
+        self._pool = None
 
     def __len__(self):
         return len(self._data) - 1
 
+    def _prefetch(self, index: int) -> None:
+        if index in self._frames or index in self._pending or not 0 <= index < len(self._data):
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gsloc-reader")
+        self._pending[index] = self._pool.submit(self._data.__getitem__, index)
+
     def _frame(self, index: int):
-        f = self._data[index]
+        if index in self._frames:
+            return self._frames[index]
+        fut = self._pending.pop(index, None)
+        f = fut.result() if fut is not None else self._data[index]
         t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=self.device)  # noqa: E731
         depth, rgb, pose = t(f.depth), t(f.rgb), t(f.pose)
-        return depth, rgb, pose, depth_to_points(depth, self.K), (rgb / 255.0).reshape(-1, 3)
+        out = (depth, rgb, pose, depth_to_points(depth, self.K), (rgb / 255.0).reshape(-1, 3))
+        self._frames[index] = out
+        for k in [k for k in self._frames if k < index - 1]:  # (a pair needs two frames: keep the last two)
+            del self._frames[k]
+        return out
 
     @torch.no_grad()
     def __getitem__(self, index: int) -> AlignData:
         if index >= len(self) or index < 0:
             raise IndexError(index)
+        ph = self.phase_seconds
+        t0 = _now(self.device) if ph is not None else 0.0
         t_depth, t_rgb, t_pose, t_pts, t_col = self._frame(index)
         s_depth, s_rgb, s_pose, s_pts, s_col = self._frame(index + 1)
+        self._prefetch(index + 2)  # what pair index + 1 will need; decoded while this pair is being tracked
         t_pts = transform_points(t_pose, t_pts)
         s_pts = transform_points(t_pose, s_pts)
         pca_factor = torch.scalar_tensor(1.0, device=self.device)
         if self.normalize:
             t_pts, t_pose, s_pts, s_pose, pca_factor = normalize_pair(t_pts, t_pose, s_pts, s_pose)
+            t1 = _now(self.device) if ph is not None else 0.0
             h, w = s_depth.shape
             s_depth = compute_depth_gt(s_pts, s_col, self.K.unsqueeze(0), c2w=t_pose.unsqueeze(0), height=h,
                                        width=w) / pca_factor
             s_depth = s_depth.reshape(h, w)
+            if ph is not None:
+                t2 = _now(self.device)
+                ph["read_backproject_normalise"] = ph.get("read_backproject_normalise", 0.0) + (t1 - t0)
+                ph["depth_gt_render"] = ph.get("depth_gt_render", 0.0) + (t2 - t1)
+        elif ph is not None:
+            ph["read_backproject_normalise"] = ph.get("read_backproject_normalise", 0.0) + (_now(self.device) - t0)
         return AlignData(pca_factor=pca_factor, colors=t_col, pixels=(s_rgb / 255.0).unsqueeze(0), tar_points=t_pts,
                          src_points=s_pts, src_depth=s_depth.unsqueeze(-1).unsqueeze(0), tar_c2w=t_pose,
                          src_c2w=s_pose, tar_nums=t_pts.shape[0])

@@ -26,9 +26,21 @@ def rmse(values: List[float]) -> float:
     return math.sqrt(sum(v * v for v in values) / max(len(values), 1))
 
 
-def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[int] = 1998, verbose: bool = False) -> Dict:
-    """Runner.train (gs_trainer_total.py:45-282): frames 0..min(len, 1998)."""
+def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[int] = 1998, verbose: bool = False,
+                  profile: bool = False) -> Dict:
+    """Runner.train (gs_trainer_total.py:45-282): frames 0..min(len, 1998).  profile=True: also the wall time per phase
+    of a frame (synchronising at the phase boundaries): reading + back-projection + PCA normalisation, the query-depth
+    render, the kNN scale initialisation, load_frame (copies + calibration pass), and the optimisation itself (graph
+    capture + replays + polls) -- `phase_seconds` in the result."""
     cfg = TrackerConfig(max_steps=num_iters)
+    phases = {} if profile else None
+    parser.phase_seconds = phases
+
+    def tick():
+        if profile:
+            torch.cuda.synchronize()
+        return time.perf_counter()
+
     tracker = None
     eTs, eRs, steps = [], [], []
     long_frames = 0  # frames with a tile list long enough to be split over workgroups (a pile of invalid-depth points)
@@ -39,9 +51,16 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
         H, W = d.src_depth.shape[1:3]
         if tracker is None or tracker.N != d.tar_points.shape[0]:
             tracker = GraphTracker(d.tar_points.shape[0], W, H, cfg, device=d.tar_points.device)
-        tracker.load_frame(d.tar_points, d.colors, init_gs_scales(d.tar_points), d.src_depth, d.tar_c2w, d.src_c2w,
-                           parser.K)
+        ta = tick()
+        scales = init_gs_scales(d.tar_points)
+        tb = tick()
+        tracker.load_frame(d.tar_points, d.colors, scales, d.src_depth, d.tar_c2w, d.src_c2w, parser.K)
+        tc = tick()
         res = tracker.run()
+        if profile:
+            td = tick()
+            for k, v in (("knn_scales", tb - ta), ("load_frame_calibrate", tc - tb), ("optimise", td - tc)):
+                phases[k] = phases.get(k, 0.0) + v
         long_frames += int(tracker.rc.long_min > 0)
         # early stop never fired before min_step: fall back to the last iterate's errors, as the reference would log inf
         eTs.append(res.best_eT)
@@ -50,6 +69,7 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
         if verbose:
             print(f"frame {i}: steps {res.steps} loss {res.best_loss:.3e} eT {res.best_eT:.3e} eR {res.best_eR:.3e}")
     dt = time.perf_counter() - t0
+    parser.phase_seconds = None
     finite = [(a, b) for a, b in zip(eTs, eRs) if math.isfinite(a) and math.isfinite(b)]
     if not finite:  # e.g. num_iters <= 101: the minimum-loss read-out starts after step 100 and never fired
         return {"ATE": float("nan"), "AAE": float("nan"), "frames": n, "frames_with_result": 0,
@@ -57,7 +77,8 @@ def evaluate_room(parser: Parser, num_iters: int = 2000, max_frames: Optional[in
                 "error": "no frame produced a minimum-loss read-out (num_iters must exceed 101)"}
     return {"ATE": rmse([a for a, _ in finite]), "AAE": rmse([b for _, b in finite]), "frames": n,
             "frames_with_result": len(finite), "mean_steps": sum(steps) / max(len(steps), 1),
-            "frames_with_long_lists": long_frames, "seconds": dt, "frames_per_s": n / dt if dt > 0 else None}
+            "frames_with_long_lists": long_frames, "seconds": dt, "frames_per_s": n / dt if dt > 0 else None,
+            **({"phase_seconds": phases} if profile else {})}
 
 
 def main(argv=None):

@@ -4,8 +4,9 @@ Same arithmetic as ``Runner.train``'s inner loop (/root/reference/src/my_gsplat/
 and as ``my_gsplat.PoseTracker``; the difference is where the glue runs: the loss (loss.py:10-59), the pose
 chain (model.py:79-82, transform.py:50-66, geometry.py:12-20), both Adam optimisers, the exponential LR
 decay and the early-stop bookkeeping (data/base.py:34-43) live in two device kernels (loss, pose step:
-csrc/tracker.hip), so one iteration is a fixed sequence of 7 launches with no allocation and no host
-synchronisation, replayed as a HIP graph.  The host looks at the device-side "stopped" flag every
+csrc/tracker.hip), so one iteration is a fixed sequence of 5 launches (projection; compositing forward, which sorts its own
+tile's bin; compositing backward, which computes its tile's loss; projection backward; pose step -- up to 8 with several
+ranks, a normal term or long tile lists) with no allocation and no host synchronisation, replayed as a HIP graph.  The host looks at the device-side "stopped" flag every
 ``poll`` iterations only.
 
 Several GPUs (``rows=``, ``group=``): every rank tracks the same pose on its tile-row strip (plus ONE pixel row
@@ -13,6 +14,14 @@ of halo on each interior side), the 12 pose-gradient entries and the two loss su
 library into one 16-float buffer, summed with ONE all-reduce per iteration, and every rank applies the identical
 update.  The iteration is then two graph-replayable halves around the collective: [render, loss, backward, pack]
 and [pose step].
+
+Strips keep only the Gaussians that can reach them: per frame every rank projects all N Gaussians once at
+the initial pose and keeps those whose splat touches its rendered tile rows widened by a guard band of ``guard_tiles``
+tile rows (parallel.gaussians_for_strip); the iteration then projects, bins and back-propagates the kept ones only.
+The guard band is CHECKED, not assumed: at every poll a projection of all N at the current pose tells whether a Gaussian
+outside the kept set now reaches the strip; the answer is MAX-reduced with the overflow flags, and on a violation every
+rank doubles its guard band, re-buckets and re-runs the frame from its initial pose (a pile of invalid-depth points
+1.5 cm in front of the camera moves 20 px per iteration: NOTES.md).
 
 Overflow handling: the kernels never drop work silently.  A splat that outgrows the tiny-splat backward raises a
 sticky device flag, and the intersection count is compared with the buffer capacity; both are read at the
@@ -33,13 +42,13 @@ from ._lib import check, current_stream, load_library, ptr
 from .context import RenderContext
 from .my_gsplat.trainer import TrackerConfig, TrackResult
 from .my_gsplat.utils import rgb_to_sh
-from .parallel import halo_pixel_rows, halo_rows
+from .parallel import gaussians_for_strip, halo_pixel_rows, halo_rows
 
 
 class GraphTracker:
     def __init__(self, N: int, width: int, height: int, config: TrackerConfig = TrackerConfig(), device="cuda",
                  render_mode: str = "RGB+ED", rows: Optional[Tuple[int, int]] = None, group=None,
-                 use_graph: bool = True, poll: int = 25):
+                 use_graph: bool = True, poll: int = 25, prune: Optional[bool] = None, guard_tiles: int = 1):
         assert render_mode in ("RGB+ED", "ED"), "the tracker's loss reads expected depth"
         self.lib = load_library()
         self.cfg = config
@@ -56,10 +65,12 @@ class GraphTracker:
         self.row0, self.row1 = self.rows[0] * 16, min(self.rows[1] * 16, self.H)
         sh_deg = config.gs.sh_degree
         self.K_sh = (sh_deg + 1) ** 2
-        self.rc = RenderContext(self.N, self.W, self.H, render_mode, sh_degree=sh_deg, K_sh=self.K_sh, device=self.dev,
-                                near_plane=config.gs.near_plane, far_plane=config.gs.far_plane,
-                                tile_rows=self.render_rows, pixel_rows=self.pixel_rows, full_grads=False,
-                                sort_in_forward=group is None)  # (every forward of an iteration has its backward)
+        # a strip keeps only the Gaussians that can reach it (+ guard band, checked at every poll): _bucket()
+        self.prune = (rows is not None) if prune is None else bool(prune)
+        self.guard0 = self.guard = max(int(guard_tiles), 0)
+        self.kept = self.kept_mask = self._active = self._check = None
+        self.rebuckets = 0  # guard-band violations recovered from (all frames)
+        self.rc = self._make_rc(self.N)
         f32 = torch.float32
         d = self.dev
         self.means = torch.zeros(self.N, 3, dtype=f32, device=d)
@@ -95,6 +106,54 @@ class GraphTracker:
         self._side = torch.cuda.Stream(device=d)
         self.headroom = 1.5
 
+    def _make_rc(self, n: int) -> RenderContext:
+        c = self.cfg
+        return RenderContext(n, self.W, self.H, self.mode, sh_degree=c.gs.sh_degree, K_sh=self.K_sh, device=self.dev,
+                             near_plane=c.gs.near_plane, far_plane=c.gs.far_plane, tile_rows=self.render_rows,
+                             pixel_rows=self.pixel_rows, full_grads=False,
+                             sort_in_forward=self.group is None)  # (every forward of an iteration has its backward)
+
+    # ------------------------------------------------------------------ strip buckets and their guard band
+    def _gauss(self):
+        """The per-Gaussian inputs of the iteration: all N, or the strip's kept subset."""
+        return self._active if self._active is not None else (self.means, self.quats, self.scales, self.opac, self.sh)
+
+    def _reach(self, guard: int) -> Tensor:
+        """[N] bool: whose splat touches this rank's rendered tile rows widened by `guard` tile rows, at the CURRENT pose
+        (one projection of all N Gaussians through the library; radii and centres only)."""
+        if self._check is None:
+            c = self.cfg
+            self._check = RenderContext(self.N, self.W, self.H, "ED", sh_degree=None, device=self.dev,
+                                        near_plane=c.gs.near_plane, far_plane=c.gs.far_plane, tile_rows=self.render_rows,
+                                        full_grads=False, reorder=False)
+        chk = self._check
+        chk._project(self.means, self.quats, self.scales, self.opac, None, self.viewmat, self.K)
+        idx = gaussians_for_strip(chk.Q0[:, 0:2], chk.radii, self.render_rows, guard_tiles=guard)
+        mask = torch.zeros(self.N, dtype=torch.bool, device=self.means.device)
+        mask[idx] = True
+        return mask
+
+    def _bucket(self) -> None:
+        """Per frame (and again after a guard-band violation): the kept set at the initial pose, a render context of its
+        size, calibrated.  Nothing visible at all (or launches refused: the CPU tests) keeps everything."""
+        mask = self._reach(self.guard)
+        idx = mask.nonzero(as_tuple=True)[0]
+        if idx.numel() == 0:
+            mask[:] = True
+            idx = mask.nonzero(as_tuple=True)[0]
+        self.kept, self.kept_mask = idx, mask
+        self._active = tuple(t[idx].contiguous() for t in (self.means, self.quats, self.scales, self.opac, self.sh))
+        n = int(idx.numel())
+        if self.rc.N != n:
+            self.rc = self._make_rc(n)
+        self.rc.calibrate(*self._active, self.viewmat, self.K, headroom=self.headroom)
+
+    def _band_violations(self) -> int:
+        """Gaussians outside the kept set whose splat reaches the rendered rows at the current pose (0 = the band held)."""
+        if not self.prune or self.kept_mask is None or bool(self.kept_mask.all()):
+            return 0
+        return int((self._reach(0) & ~self.kept_mask).sum())
+
     # ------------------------------------------------------------------ frame setup
     def load_frame(self, tar_points: Tensor, colors: Tensor, scales: Tensor, src_depth: Tensor, tar_c2w: Tensor,
                    src_c2w: Tensor, K: Tensor) -> None:
@@ -118,8 +177,12 @@ class GraphTracker:
         cam = self.cfg.camera
         check(self.lib.gsl_pose_init(ptr(self.pose_f), ptr(self.pose_i), ptr(self.init_c2w), cam.quat_lr, cam.trans_lr,
                                      ptr(self.c2w), ptr(self.viewmat), current_stream()), "gsl_pose_init")
-        self.rc.calibrate(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K,
-                          headroom=self.headroom)
+        self.guard = self.guard0
+        if self.prune:
+            self._bucket()
+        else:
+            self.rc.calibrate(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K,
+                              headroom=self.headroom)
         self.graph = self.graph_tail = None  # capacity buffers may have been reallocated
 
     # ------------------------------------------------------------------ one iteration
@@ -128,7 +191,7 @@ class GraphTracker:
         and memsets only: safe to capture."""
         cfg, lib = self.cfg, self.lib
         st = current_stream()
-        self.rc.forward(self.means, self.quats, self.scales, self.opac, self.sh, self.viewmat, self.K)
+        self.rc.forward(*self._gauss(), self.viewmat, self.K)
         edge_w = 1.0 - cfg.depth_lambda - cfg.normal_lambda
         # one rank, no normal term, tiny-splat backward: the compositing backward computes the loss of its own tile and
         # its gradient (gsl_tiny_raster_bwd(..., loss_depth_gt, ...)): one launch fewer per iteration
@@ -255,14 +318,15 @@ class GraphTracker:
             dst.copy_(src)
 
     # ------------------------------------------------------------------ frame loop
-    def _poll(self) -> Tuple[int, int, int, int, int]:
+    def _poll(self) -> Tuple[int, int, int, int, int, int]:
         """The only host sync of the loop: (stopped, intersections beyond the capacity or 0, a splat outgrew the tiny
-        backward, longest tile list that outgrew its bin or 0, segments of long tile lists beyond their workspace or 0).  With several ranks the four numbers are MAX-reduced
-        over the group, so every rank takes the same decision at the same iteration: a rank that re-ran the frame on
-        its own while the others returned would pair its all-reduces with those of a different iteration or frame."""
+        backward, longest tile list that outgrew its bin or 0, segments of long tile lists beyond their workspace or 0,
+        Gaussians that left their strip's guard band or 0).  With several ranks the numbers are MAX-reduced over the
+        group, so every rank takes the same decision at the same iteration: a rank that re-ran the frame on its own while
+        the others returned would pair its all-reduces with those of a different iteration or frame."""
         n_is = int(self.rc.n_is.item())
         local = [int(self.pose_i[2].item()), n_is if n_is > self.rc.capacity else 0, int(self.rc.tiny_overflowed()),
-                 int(self.rc.bins_overflowed()), int(self.rc.long_overflowed())]
+                 int(self.rc.bins_overflowed()), int(self.rc.long_overflowed()), self._band_violations()]
         if self.group is None:
             return tuple(local)
         import torch.distributed as dist
@@ -274,7 +338,7 @@ class GraphTracker:
     def run(self) -> TrackResult:
         """Optimise the loaded frame until early stop or max_steps.  Returns the reference's read-outs."""
         start = [t.clone() for t in self._state()]
-        for attempt in range(4):
+        for attempt in range(8):
             if self.use_graph and self.graph is None:
                 self._capture()
             done, redo = 0, False
@@ -283,8 +347,8 @@ class GraphTracker:
                 for _ in range(n):
                     self._iteration()
                 done += n
-                stopped, n_over, tiny_over, bin_over, long_over = self._poll()
-                if n_over or tiny_over or bin_over or long_over:
+                stopped, n_over, tiny_over, bin_over, long_over, band_over = self._poll()
+                if n_over or tiny_over or bin_over or long_over or band_over:
                     redo = True
                     break
                 if stopped:
@@ -309,8 +373,15 @@ class GraphTracker:
             self.graph = self.graph_tail = None
             for dst, src in zip(self._state(), start):
                 dst.copy_(src)
+            if band_over:
+                # a Gaussian outside the kept set reached the strip: the gradient of the iterations since the last poll
+                # missed it.  Every rank (the decision was reduced) widens its guard band and buckets again at the
+                # frame's initial pose, which the state copy above has just restored.
+                self.guard = max(2 * self.guard, 1)
+                self.rebuckets += 1
+                self._bucket()
         else:
-            raise RuntimeError("the frame kept overflowing its buffers after three recalibrations")
+            raise RuntimeError("the frame kept overflowing its buffers (or leaving its guard band) after seven recoveries")
         pi = self.pose_i.tolist()
         pf = self.pose_f.tolist()
         res = TrackResult()

@@ -100,6 +100,23 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float sv) {
         if (KIND == 74) asm volatile("v_cmp_le_f32_e64 s[20:21], %0, %1" :: "v"(a[i]), "s"(sv) : "s20", "s21");
         if (KIND == 75) asm volatile("v_bitop3_b32 %0, %0, %1, %0 bitop3:0x80" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
         if (KIND == 76) asm volatile("v_subrev_co_u32_e64 %0, s[20:21], 1, %0" : "+v"(u[i]) :: "s20", "s21");
+        // third batch: shifts and a few more integer forms
+        if (KIND == 77) asm volatile("v_lshlrev_b32 %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 78) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(u[i]));
+        if (KIND == 79) asm volatile("v_ashrrev_i32 %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 80) asm volatile("v_not_b32 %0, %0" : "+v"(u[i]));
+        if (KIND == 81) asm volatile("v_and_b32 %0, 15, %0" : "+v"(u[i]));
+        if (KIND == 82) asm volatile("v_add_u32 %0, 16, %0" : "+v"(u[i]));
+        if (KIND == 83) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 84) asm volatile("v_add_lshl_u32 %0, %0, %1, 2" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 85) asm volatile("v_and_or_b32 %0, %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 86) asm volatile("v_cvt_u32_f32 %0, %0" : "+v"(a[i]));
+        if (KIND == 87) asm volatile("v_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xc" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+        if (KIND == 88) asm volatile("v_fma_f32 %0, %0, %0, %0 clamp" : "+v"(a[i]));
+        if (KIND == 89) asm volatile("v_mul_f32_e64 %0, %0, %0 mul:2" : "+v"(a[i]));
+        if (KIND == 90) asm volatile("v_xad_u32 %0, %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 91) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
+        if (KIND == 92) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[i]) : "v"(u[(i + 1) & 7]));
         if (KIND == 34) { float4 q; asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"(lbase)); if (i == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a[0] += q.x; } }
         if (KIND == 35) { float q; asm volatile("ds_read_u8 %0, %1" : "=v"(q) : "v"(laddr)); if (i == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a[0] += q; } }
         if (KIND == 36) { float4 q; asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"(lrand)); if (i == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a[0] += q.x; } }
@@ -150,5 +167,9 @@ int main() {
     run<67>("v_fmaak_f32", d, b); run<68>("v_lshlrev_b32_sdwa", d, b); run<69>("v_readfirstlane", d, b); run<70>("v_bfi_b32", d, b);
     run<71>("v_mul_f32 inline 0.5", d, b); run<72>("v_add_f32 2 distinct", d, b); run<73>("v_mul_lo_u32", d, b); run<74>("v_cmp_e64 sgpr operand", d, b);
     run<75>("v_bitop3_b32", d, b); run<76>("v_subrev_co_u32", d, b);
+    run<77>("v_lshlrev_b32 vgpr", d, b); run<78>("v_lshrrev_b32 imm", d, b); run<79>("v_ashrrev_i32 vgpr", d, b); run<80>("v_not_b32", d, b);
+    run<81>("v_and_b32 inline int", d, b); run<82>("v_add_u32 inline int", d, b); run<83>("v_mul_u32_u24", d, b); run<84>("v_add_lshl_u32", d, b);
+    run<85>("v_and_or_b32", d, b); run<86>("v_cvt_u32_f32", d, b); run<87>("v_add_f32_dpp bank_mask", d, b); run<88>("v_fma_f32 clamp", d, b);
+    run<89>("v_mul_f32 omod", d, b); run<90>("v_xad_u32", d, b); run<91>("v_min_u32", d, b); run<92>("v_ldexp_f32", d, b);
   }
 }

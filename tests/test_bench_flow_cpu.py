@@ -67,4 +67,5 @@ def test_failing_side_measurements_do_not_cost_the_headline_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "Gaussians/s" and cb["value"] > 0 and cb["cores"] >= 1
     assert "gsplat_oracle.c" in cb["sample"] and "N=20000" in cb["sample"]
-    assert "error" in d["pose_opt"] and all("error" in v for v in d["variants"]) and len(d["variants"]) == 4
+    assert "error" in d["pose_opt"] and all("error" in v for v in d["variants"]) and len(d["variants"]) == 5
+    assert "error" in d["api"] and "error" in d["frame"]  # (the boundary and per-frame side measurements need the GPU too)

@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 THREADS = min(os.cpu_count() or 1, 16)
 
 
-def _context_vs_c_oracle(tag, sc, V, W, H, v, max_flipped, grad_names=("means", "scales", "opacities")):
+def _context_vs_c_oracle(tag, sc, V, W, H, v, max_flipped, grad_names=("means", "scales", "opacities"),
+                         with_deterministic=True):
     """RenderContext forward + backward against the C oracle on the same inputs; returns the error report."""
     from gsplatloc_amd.context import RenderContext
     from oracle import c_oracle as C
@@ -52,40 +53,56 @@ def _context_vs_c_oracle(tag, sc, V, W, H, v, max_flipped, grad_names=("means", 
     # float64 oracle, HIP against the oracle's float32 build (like for like), and the float32 floor of the
     # configuration (the oracle's float32 build against its float64 build).
     upstreams = v if isinstance(v, (list, tuple)) else [v]
-    pose_err = hip_vs_f32 = floor32 = 0.0
+    pose_err = hip_vs_f32 = floor32 = det_err = 0.0
     grads = want = None
+    # the same backward without float atomics (fixed summation order): separates "the atomics' order moved the sum" from
+    # "the records are rounded" in the pose-gradient figure.  Not for the 5 M scene (memory, time).
+    det = None
+    if with_deterministic and N <= 1_100_000:
+        det = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False, deterministic=True,
+                            reorder=False)
+        det.calibrate(*inp)
     for vk in upstreams:
         vm = vk * ok[..., None]
         want = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f64",
                                threads=THREADS)
         ctx.forward(*inp)
         grads = ctx.backward(vm.float().to(dev).contiguous(), torch.zeros(H, W, 1, device=dev), full=True)
+        grads = ctx.grads_in_input_order(grads)  # (random-order input: the context placed the Gaussians in tile order)
         torch.cuda.synchronize()
         ctx.check_capacity()
         want32 = C.rasterization(*cpu, V, sc["K"], W, H, sh_degree=1, render_mode="RGB+ED", v_render=vm, precision="f32",
                                  threads=THREADS)
+        if det is not None:
+            det.forward(*inp)
+            gd = det.backward(vm.float().to(dev).contiguous(), torch.zeros(H, W, 1, device=dev), full=False)
+            torch.cuda.synchronize()
+            det_err = max(det_err, rel_inf(gd["viewmat"][:3], want["v_viewmat"][:3]))
         pose_err = max(pose_err, rel_inf(grads["viewmat"][:3], want["v_viewmat"][:3]))
         hip_vs_f32 = max(hip_vs_f32, rel_inf(grads["viewmat"][:3], want32["v_viewmat"][:3]))
         floor32 = max(floor32, rel_inf(want32["v_viewmat"][:3], want["v_viewmat"][:3]))
     errs = dict(render_rel_median=float(qs[0]), render_rel_p99=float(qs[1]), depth_rel=depth_rel, alpha_abs=alpha_abs,
                 v_viewmat=pose_err, v_viewmat_vs_f32_oracle=hip_vs_f32, v_viewmat_f32_oracle_vs_f64=floor32,
                 upstream_seeds=float(len(upstreams)))
+    if det is not None:
+        errs["v_viewmat_deterministic"] = det_err
+        del det
     for name in grad_names:  # (of the last upstream)
         a, b = grads[name].cpu().double().numpy().reshape(-1), want["v_" + name].reshape(-1)
         errs["v_" + name] = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     report(tag, flipped, **errs)
     assert floor32 < FLOOR32_MAX, f"{tag}: the float32 floor itself is {floor32:.2e}"
-    assert pose_err < pose_grad_bound(floor32), f"{tag}: pose gradient {pose_err:.2e} (float32 floor {floor32:.2e})"
+    kind = "X" if N > 1_100_000 else ("sigma1" if tag.startswith("R") and "sigma=1.0" in tag else "subpixel")
+    assert pose_err < pose_grad_bound(floor32, kind), f"{tag}: pose gradient {pose_err:.2e} (float32 floor {floor32:.2e})"
     for name in grad_names:  # relative L2 over all Gaussians; a splat whose own alpha sits on 1/255 at a nearly opaque
         assert errs["v_" + name] < 5e-3, (tag, name, errs["v_" + name])  # pixel switches without moving the pixel
     return errs
 
 
 def _depth_upstream(H, W, seed=1):
-    g = torch.Generator().manual_seed(seed)
-    v = torch.zeros(H, W, 4, dtype=torch.float64)
-    v[..., 3] = torch.randn(H, W, generator=g, dtype=torch.float64)
-    return v
+    """The bench's upstream gradient (same generator, dtype and seed: gsplatloc_amd.synthetic.depth_upstream)."""
+    from gsplatloc_amd.synthetic import depth_upstream
+    return depth_upstream(H, W, seed).double()
 
 
 @pytest.mark.parametrize("N,W,H,sigma_px,order,max_flipped", [
@@ -224,20 +241,27 @@ def test_config_X_fp16_staged_compositing():
     assert pose < 2e-2, pose  # the gradient of a render whose records carry 5e-4 relative rounding
 
 
-@pytest.mark.parametrize("stride,holes", [(3, False), (1, True)])
-def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
+@pytest.mark.parametrize("workload", ["S", "T", "D", "R"])
+def test_tracker_loss_pose_gradient_at_config_sizes(workload):
     """north_star's pose-gradient statement as the tracker poses it: d loss / d viewmat of GsplatLoc's depth + Sobel
     loss (/root/reference/src/my_gsplat/gs_trainer_total.py:105-150) on the frames of configs S (102 400 Gaussians) and
-    T (307 200, invalid depths), 640x480, HIP (render, fused loss kernel, backward) against the oracle (C rasterizer
-    in float64 + the restated loss under autograd).  1e-4 of the largest entry."""
+    T (307 200, invalid depths), 640x480, and -- round 4 -- at the metric's size: D (816 000 Gaussians of a 1200x680
+    depth frame) and R (1 M random Gaussians, 1200x680); HIP (render, fused loss kernel, backward) against the oracle
+    (C rasterizer in float64 + the restated loss under autograd).  1e-4 of the largest entry is north_star's figure;
+    what is measured, and the float32 floor next to it, is printed and bounded (tests/parity.py)."""
     from gsplatloc_amd._lib import check, current_stream, load_library, ptr
     from gsplatloc_amd.context import RenderContext
-    from gsplatloc_amd.synthetic import depth_frame_scene
+    from gsplatloc_amd.synthetic import depth_frame_scene, perturbed_pose, random_scene
     from oracle import tracker_oracle as T
 
     dev = torch.device("cuda")
-    W, H = 640, 480
-    sc = depth_frame_scene(W, H, stride=stride, holes=holes, device=dev)
+    if workload == "R":
+        W, H = 1200, 680
+        sc = random_scene(1_000_000, W, H, sigma_px=1.0, device=dev)
+        sc["viewmat"] = torch.linalg.inv(perturbed_pose()).to(dev).contiguous()
+    else:
+        W, H = (1200, 680) if workload == "D" else (640, 480)
+        sc = depth_frame_scene(W, H, stride=3 if workload == "S" else 1, holes=workload == "T", device=dev)
     N = sc["means"].shape[0]
     inp = (sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], sc["viewmat"], sc["K"].contiguous())
     # target depth: the same cloud seen from a slightly different pose (any fixed image would do)
@@ -267,7 +291,7 @@ def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
         total[precision].backward()
         grad[precision] = Vo.grad[:3].clone()
     err, floor32 = rel_inf(got[:3], grad["f64"]), rel_inf(grad["f32"], grad["f64"])
-    report(f"tracker-loss pose gradient, {N} Gaussians 640x480", 0.0,
+    report(f"tracker-loss pose gradient, {workload}: {N} Gaussians {W}x{H}", 0.0,
            loss_rel=abs(loss_g - float(total["f64"])) / float(total["f64"]), v_viewmat=err,
            v_viewmat_vs_f32_oracle=rel_inf(got[:3], grad["f32"]), v_viewmat_f32_oracle_vs_f64=floor32)
     assert abs(loss_g - float(total["f64"])) < 1e-4 * float(total["f64"])
@@ -275,7 +299,7 @@ def test_tracker_loss_pose_gradient_at_config_sizes(stride, holes):
     # flips the sign of that pixel's term, so the gradient carries a float32 floor well above the loss's own.  The
     # bound follows the measured floor but is capped, and the floor itself is bounded (tests/parity.py).
     assert floor32 < FLOOR32_MAX, floor32
-    assert err < max(POSE_GRAD_TOL, min(2.0 * floor32, 1e-3)), (err, floor32)
+    assert err < pose_grad_bound(floor32, "subpixel"), (err, floor32)
 
 
 def test_long_tile_list_is_split_over_workgroups_and_matches_the_oracle():

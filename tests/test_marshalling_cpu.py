@@ -297,3 +297,54 @@ def test_graph_tracker_overflow_on_one_rank_is_recovered_by_all(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
+
+
+GROUP_BAND = GROUP_RANK[:GROUP_RANK.index("# what gsl_pack_pose_reduce would have left")] + """
+# A Gaussian leaves the guard band of ONE strip (rank 0 reports 3 violators at its first poll): the count is MAX-reduced
+# with the overflow flags, so BOTH ranks widen their band, bucket again at the initial pose and re-run the frame
+# together -- their collectives stay paired (SURVEY.md 8e: "fall back ... if a splat leaves its band").
+assert gt.prune and gt.guard == 1 and gt.kept_mask is not None
+gt.use_graph = False
+fired = [False]
+def violations():
+    if rank == 0 and not fired[0]:
+        fired[0] = True
+        return 3
+    return 0
+gt._band_violations = violations
+buckets = [0]
+real_bucket = gt._bucket
+def counted_bucket():
+    buckets[0] += 1
+    real_bucket()
+gt._bucket = counted_bucket
+n_coll = [0]
+real = gt._collective
+def counted():
+    n_coll[0] += 1
+    real()
+gt._collective = counted
+res = gt.run()
+assert n_coll[0] == 10, n_coll          # 5 iterations, recovery, 5 iterations again -- on BOTH ranks
+assert gt.guard == 2 and gt.rebuckets == 1 and buckets[0] == 1, (gt.guard, gt.rebuckets, buckets)
+print(f"rank {rank} ok", flush=True)
+dist.destroy_process_group()
+"""
+
+
+def test_graph_tracker_guard_band_violation_on_one_rank_rebuckets_all(tmp_path):
+    """SURVEY.md 8(e) / VERDICT r3 item 6: strips keep only the Gaussians within their guard band, and the band is
+    checked at every poll.  Two gloo ranks, a violation reported on rank 0 only: both ranks double the band, bucket
+    again and redo the frame (10 collectives each)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "group_band.py"
+    script.write_text(GROUP_BAND)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29549", str(script), root]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
