@@ -46,19 +46,35 @@ __device__ __forceinline__ float g16_sel(unsigned long long m, float t, float f)
 
 // Reduce-scatter of 8 values over a 16-lane DPP row: returns, in lane p, the row total of value (p >> 1)
 // (even and odd lane of a pair hold the same total).  4 + 2 + 1 exchange steps with halving payload + 1 plain add.
+//
+// Round 4: the first two steps select by BANK (lanes 0-7 | 8-15, then bit 2 of p: banks {0,2} | {1,3}), and a DPP
+// instruction takes a bank mask for its destination write.  So instead of two v_cndmask (keep / send) + one v_add_f32_dpp
+// per output, the first add writes  x + x[partner]  of one value in every lane and a second add with the complementary
+// bank mask overwrites the other banks with the same sum of the other value: 2 instead of 3 four-cycle VALU per output, 12
+// instead of 18 for the two steps (every v_cndmask, DPP and SGPR-operand op issues in 4 cycles on gfx950, plain
+// fma / add / mul in 2: profiles/r04_valu_issue.txt).  a + b and b + a are the same float: the sums are bit-identical to
+// the select form's.  The instructions are inline asm (the compiler folds a v_mov_dpp into an add only with a full bank
+// mask), so the "VALU write -> DPP read of the same VGPR needs 2 wait states" hazard is handled here: s_nop 1 in front,
+// and every later read is at least three instructions behind its write.
 __device__ __forceinline__ float row_scatter8(const float (&v)[8]) {
-  float n[4], m[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float keep = g16_sel(G16_M_LO8, v[i], v[i + 4]), send = g16_sel(G16_M_LO8, v[i + 4], v[i]);
-    n[i] = keep + dpp_get<0x140>(send);  // row_mirror: p <-> 15 - p
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    float keep = g16_sel(G16_M_B2, n[i], n[i + 2]), send = g16_sel(G16_M_B2, n[i + 2], n[i]);
-    m[i] = keep + dpp_get<0x141>(send);  // row_half_mirror: p <-> 7 - p inside each half row
-  }
-  float keep = g16_sel(G16_M_B1, m[0], m[1]), send = g16_sel(G16_M_B1, m[1], m[0]);
+  float n0, n1, n2, n3, m0, m1;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\t"   // p <-> 15 - p; lanes 0-7 end with values 0-3,
+      "v_add_f32_dpp %1, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %9, %9 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"  // ... lanes 8-15 with values 4-7
+      "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"  // p <-> 7 - p inside each half row
+      "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"  // banks 1, 3 (bit 2 of p set)
+      "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(m0), "=&v"(m1)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+  float keep = g16_sel(G16_M_B1, m0, m1), send = g16_sel(G16_M_B1, m1, m0);
   float r = keep + dpp_get<0x4E>(send);  // quad_perm [2,3,0,1]
   r += dpp_get<0xB1>(r);                 // quad_perm [1,0,3,2]
   return r;

@@ -113,6 +113,14 @@ __device__ __forceinline__ unsigned row_or(unsigned v) {
   return v;
 }
 
+// Index of the lowest set bit; 0xFFFFFFFF for 0 (v_ffbl_b32 as it is: __builtin_ctz(0) is undefined and __ffs costs two more
+// four-cycle instructions for the zero case, which the trips below do not need).
+__device__ __forceinline__ int ffbl_raw(unsigned v) {
+  int r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 __device__ __forceinline__ void box_range(float centre_rel, float r, int& lo, int& hi) {
   // pixel centres of the quadrant sit at 0..7 in these coordinates
   float l = ceilf(centre_rel - r), h = floorf(centre_rel + r);
@@ -183,21 +191,29 @@ __device__ __forceinline__ void praster_walk(
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         unsigned m = half ? mhi : mlo;
+        if (half) m = done ? 0u : m;  // (a pixel that stopped in the first half; inside the loop only m is cleared)
+        const uint16_t* const ql = &sb.qlist[wv][c + half * 32];
         // Straight-line trips under a wave-uniform loop: a lane that has run out of candidates goes through the
         // arithmetic with alpha 0.  No divergent region, so none of the copies the structurizer makes of the nine values
         // that live across the loop (they were a quarter of the VALU instructions of a trip written with branches:
         // 110 -> 80 per trip, forward 175 -> 166 us at R).  Two candidates per trip: both records are requested and
         // both alphas evaluated before the transmittance updates are applied in list order (halves the dependent LDS
         // round trips).
+        // Round 4 (profiles/r04_valu_issue.txt: v_cndmask / v_cmp / v_ffbl / carry-out ops issue in 4 cycles, and / xor /
+        // sub / fma / mul in 2): the candidates are popped as one-bit MASKS (m & -m: two 2-cycle ops), which also are what
+        // the "composited" mask collects; the index of a lane WITHOUT a candidate is left as v_ffbl gives it (-1: the
+        // list slot in front of the chunk's, some valid slot of the batch whose alpha is multiplied away) instead of
+        // being selected into range; the last composited index is taken from the composited mask once per chunk, not
+        // selected per trip.  72 -> 62 VALU per trip, ten of the twelve removed ones of the 4-cycle kind.
         while (__ballot(m != 0)) {
           const bool act = m != 0;
-          const int bit0 = (__ffs((int)m) - 1) & 31;
-          m &= m - 1;
-          const bool two = m != 0;
-          const int bit1 = two ? __ffs((int)m) - 1 : bit0;
-          m &= m - 1;
-          const int t0 = sb.qlist[wv][c + half * 32 + bit0] & 255;
-          const int t1 = sb.qlist[wv][c + half * 32 + bit1] & 255;
+          const unsigned b0 = m & (0u - m);
+          m ^= b0;
+          const unsigned b1 = m & (0u - m);
+          m ^= b1;
+          const bool two = b1 != 0u;
+          const int t0 = ql[ffbl_raw(b0)] & 255;
+          const int t1 = ql[ffbl_raw(b1)] & 255;
           float4 p0 = sb.s0[t0], p1 = sb.s1[t0];
           float4 u0 = sb.s0[t1], u1 = sb.s1[t1];
           float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
@@ -234,14 +250,17 @@ __device__ __forceinline__ void praster_walk(
             pix[D - 1] += u0.z * vis1;
           }
           const bool c0 = vis0 > 0.f, c1 = vis1 > 0.f;  // composited (alpha >= 1/255 and T > 1e-4: the product is > 0)
-          const int tsel = c1 ? t1 : t0;
-          cur_idx = (c0 || c1) ? (int)bstart + tsel : cur_idx;
-          cm[half] |= ((c0 ? 1u : 0u) << bit0) | ((c1 ? 1u : 0u) << bit1);
+          cm[half] |= (c0 ? b0 : 0u) | (c1 ? b1 : 0u);
           const bool stop = stop0 || stop1;
           done = done || stop;
           m = stop ? 0u : m;
-          mhi = stop ? 0u : mhi;
         }
+      }
+      {  // the last entry this pixel composited in the chunk = the highest bit of its composited mask (list order)
+        const bool any = (cm[0] | cm[1]) != 0u;
+        const int pos = cm[1] ? 63 - __clz((int)cm[1]) : 31 - __clz((int)(cm[0] | 1u));
+        const int tl = sb.qlist[wv][c + pos] & 255;
+        cur_idx = any ? (int)bstart + tl : cur_idx;
       }
       if (isect_hits) {
         // per DPP row (= 4x4 block): OR of the pixels' composited-candidate masks; lane e then owns candidate c + e
