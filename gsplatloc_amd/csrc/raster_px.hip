@@ -39,7 +39,9 @@ struct PStage {
 // Order-preserving compaction of the staged batch into per-quadrant candidate lists.
 // Call with the record of slot `tid` (valid_rec = slot < bsize).  Two barriers inside.
 // Returns the number of candidates of quadrant `wv`.
-template <typename Stage>
+// SHIFT = 4: the lists hold the records' BYTE offsets (slot x 16) -- what a trip of praster_walk adds to the array base,
+// sparing it a 4-cycle shift per candidate; 0: slot numbers (k_tiny_bwd compares them with list positions).
+template <int SHIFT = 0, typename Stage>
 __device__ __forceinline__ int compact_quadrants(Stage& sb, int tid, bool valid_rec, float x, float y, float r,
                                                  float tile_x0, float tile_y0) {
   int lane = tid & 63, wv = tid >> 6;
@@ -60,7 +62,7 @@ __device__ __forceinline__ int compact_quadrants(Stage& sb, int tid, bool valid_
     if ((B[q] >> lane) & 1ull) {
       int base = 0;
       for (int w = 0; w < wv; ++w) base += sb.qcnt[w][q];
-      sb.qlist[q][base + __popcll(B[q] & lt)] = (uint16_t)tid;
+      sb.qlist[q][base + __popcll(B[q] & lt)] = (uint16_t)(tid << SHIFT);
     }
   }
   __syncthreads();
@@ -121,6 +123,11 @@ __device__ __forceinline__ int ffbl_raw(unsigned v) {
   return r;
 }
 
+// record at byte offset `off` (slot x 16) of a staged array
+__device__ __forceinline__ float4 rec_at(const float4* arr, unsigned off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(arr) + off);
+}
+
 __device__ __forceinline__ void box_range(float centre_rel, float r, int& lo, int& hi) {
   // pixel centres of the quadrant sit at 0..7 in these coordinates
   float l = ceilf(centre_rel - r), h = floorf(centre_rel + r);
@@ -172,15 +179,15 @@ __device__ __forceinline__ void praster_walk(
       sb.s1[tid] = make_float4(0.f, 0.f, 0.f, -1.f);
       if (RGB && MODE == 0) sb.s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    int n = compact_quadrants(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
+    int n = compact_quadrants<4>(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     for (int c = 0; c < n; c += 64) {
       if (__all(done)) break;
       int e = c + lane;
       int lox = 1, hix = 0, loy = 1, hiy = 0;
       if (e < n) {
-        int t = sb.qlist[wv][e];
-        float4 a0 = sb.s0[t];
-        float r = sb.s1[t].w;
+        const unsigned off = sb.qlist[wv][e];  // (byte offset of the record: slot x 16)
+        float4 a0 = rec_at(sb.s0, off);
+        float r = rec_at(sb.s1, off).w;
         box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
         box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
       }
@@ -212,10 +219,10 @@ __device__ __forceinline__ void praster_walk(
           const unsigned b1 = m & (0u - m);
           m ^= b1;
           const bool two = b1 != 0u;
-          const int t0 = ql[ffbl_raw(b0)] & 255;
-          const int t1 = ql[ffbl_raw(b1)] & 255;
-          float4 p0 = sb.s0[t0], p1 = sb.s1[t0];
-          float4 u0 = sb.s0[t1], u1 = sb.s1[t1];
+          const unsigned t0 = ql[ffbl_raw(b0)] & 0xFF0u;  // byte offsets (masked: a lane without a candidate reads
+          const unsigned t1 = ql[ffbl_raw(b1)] & 0xFF0u;  // whatever sits in front of the chunk's list)
+          float4 p0 = rec_at(sb.s0, t0), p1 = rec_at(sb.s1, t0);
+          float4 u0 = rec_at(sb.s0, t1), u1 = rec_at(sb.s1, t1);
           float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
           float sg0 = fmaf(p1.y * dx0, dy0, fmaf(p1.x * dx0, dx0, p1.z * dy0 * dy0));  // log2(e) sigma (see the staging)
           float sg1 = fmaf(u1.y * dx1, dy1, fmaf(u1.x * dx1, dx1, u1.z * dy1 * dy1));
@@ -240,7 +247,7 @@ __device__ __forceinline__ void praster_walk(
           const float vis1 = stop1 ? 0.f : a1 * T1;
           T = stop1 ? T1 : nT1;
           if (RGB) {
-            float4 q20 = sb.s2[t0], q21 = sb.s2[t1];  // (r, g, b, depth)
+            float4 q20 = rec_at(sb.s2, t0), q21 = rec_at(sb.s2, t1);  // (r, g, b, depth)
             pix[0] += q20.x * vis0; pix[1] += q20.y * vis0; pix[2] += q20.z * vis0;
             if (DEPTH) pix[D - 1] += q20.w * vis0;
             pix[0] += q21.x * vis1; pix[1] += q21.y * vis1; pix[2] += q21.z * vis1;
@@ -249,7 +256,9 @@ __device__ __forceinline__ void praster_walk(
             pix[D - 1] += p0.z * vis0;
             pix[D - 1] += u0.z * vis1;
           }
-          const bool c0 = vis0 > 0.f, c1 = vis1 > 0.f;  // composited (alpha >= 1/255 and T > 1e-4: the product is > 0)
+          // composited <=> alpha >= 1/255 and the pixel did not stop on this entry (alpha T > 0 then: T > 1e-4); as mask
+          // logic on the compare results already there, not as two more compares of vis
+          const bool c0 = ok0 && !stop0, c1 = ok1 && !stop0 && !stop1;
           cm[half] |= (c0 ? b0 : 0u) | (c1 ? b1 : 0u);
           const bool stop = stop0 || stop1;
           done = done || stop;
@@ -259,7 +268,7 @@ __device__ __forceinline__ void praster_walk(
       {  // the last entry this pixel composited in the chunk = the highest bit of its composited mask (list order)
         const bool any = (cm[0] | cm[1]) != 0u;
         const int pos = cm[1] ? 63 - __clz((int)cm[1]) : 31 - __clz((int)(cm[0] | 1u));
-        const int tl = sb.qlist[wv][c + pos] & 255;
+        const int tl = (sb.qlist[wv][c + pos] & 0xFF0u) >> 4;
         cur_idx = any ? (int)bstart + tl : cur_idx;
       }
       if (isect_hits) {
@@ -275,7 +284,7 @@ __device__ __forceinline__ void praster_walk(
           nib |= (unsigned)((gm >> lane) & 1ull) << g;
         }
         unsigned long long Rm = __ballot(nib != 0);  // (a set bit implies e < n)
-        if (nib) qout[n_hits + __popcll(Rm & ((1ull << lane) - 1ull))] = (nib << 28) | (unsigned)((int)bstart + sb.qlist[wv][e]);
+        if (nib) qout[n_hits + __popcll(Rm & ((1ull << lane) - 1ull))] = (nib << 28) | (unsigned)((int)bstart + (sb.qlist[wv][e] >> 4));
         n_hits += __popcll(Rm);
       }
     }
