@@ -159,6 +159,11 @@ class RenderContext:
 
     # ------------------------------------------------------------------ tile-order placement
     REORDER_MIN_N = 65536  # below this the whole record set sits in one XCD's L2 anyway
+    # above this the sorts' relabelling gather (4 bytes per list entry from a table of 4 N bytes, in random order) leaves
+    # the 4 MiB L2: measured at 5 M Gaussians / 1920x1080 the sort goes 163 -> 363 us, more than projection and compositing
+    # gain (step 1.53 -> 1.64 ms); at 2 M it is a draw (0.768 -> 0.759 ms); at 1 M a win (0.579 -> 0.543 ms).  Carrying the
+    # slot through the sort as a payload instead of gathering it afterwards is the way past this -- not built.
+    REORDER_MAX_N = 1_500_000
 
     def _choose_placement(self) -> bool:
         """Tile-order placement of the Gaussians, once per frame (the inputs are static while the pose is optimised:
@@ -172,7 +177,7 @@ class RenderContext:
         buffers) is then in STORAGE order: use grads_in_input_order() / order_ids."""
         want = self.reorder
         if want is None:
-            want = (os.environ.get("GSLOC_REORDER", "1") != "0" and self.N >= self.REORDER_MIN_N
+            want = (os.environ.get("GSLOC_REORDER", "1") != "0" and self.REORDER_MIN_N <= self.N <= self.REORDER_MAX_N
                     and not self.deterministic and not self._screen_coherent_order())
         if not want or self.N < 2:
             return False

@@ -19,7 +19,9 @@
 
 namespace gsl {
 
+#ifndef GSL_F_BIN_THREADS
 #define GSL_F_BIN_THREADS 512
+#endif
 #define GSL_F_MAX_STRIP_TILES 8192
 
 // Radius of the smallest disc around the centre that holds the whole alpha >= 1/255 ellipse {sigma <= tau}:

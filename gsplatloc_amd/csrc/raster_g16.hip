@@ -67,13 +67,14 @@ __device__ __forceinline__ float row_scatter8(const float (&v)[8]) {
       "v_add_f32_dpp %0, %10, %10 row_mirror row_mask:0xf bank_mask:0xc\n\t"  // ... lanes 8-15 with values 4-7
       "v_add_f32_dpp %1, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
       "v_add_f32_dpp %2, %12, %12 row_mirror row_mask:0xf bank_mask:0xc\n\t"
-      "v_add_f32_dpp %3, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      // (value 7 is padding -- NS = 8 only for the 7 sums of the depth-only body -- so lanes 8-15 of n3 may keep the sums
+      // of value 3: they end up in the slot of value 7, which nobody reads)
       "v_add_f32_dpp %4, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"  // p <-> 7 - p inside each half row
       "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
       "v_add_f32_dpp %4, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"  // banks 1, 3 (bit 2 of p set)
       "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
       : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3), "=&v"(m0), "=&v"(m1)
-      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]));
   float keep = g16_sel(G16_M_B1, m0, m1), send = g16_sel(G16_M_B1, m1, m0);
   float r = keep + dpp_get<0x4E>(send);  // quad_perm [2,3,0,1]
   r += dpp_get<0xB1>(r);                 // quad_perm [1,0,3,2]
@@ -306,6 +307,7 @@ __device__ __forceinline__ void qraster_bwd_body(
           }
 #pragma unroll
           for (int q = NV; q < NS; ++q) val[q] = 0.f;
+          static_assert(NS != 8 || NV == 7, "row_scatter8 treats value 7 as padding");
           if (NS == 8) r = row_scatter8(reinterpret_cast<const float(&)[8]>(val));
           else r = row_scatter16(reinterpret_cast<const float(&)[16]>(val));
         }

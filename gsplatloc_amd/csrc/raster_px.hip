@@ -166,18 +166,31 @@ __device__ __forceinline__ void praster_walk(
       int g = flatten_ids[bstart + tid];
       float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
       load_record(Q0, Q1, Q2, Qh, g, RGB && MODE == 0, r0, r1, r2);
-      sb.s0[tid] = r0;
       // staged for the walk: the conic times log2(e) (and its diagonal halved), so that a trip gets
       // log2(e) sigma = a' dx^2 + c' dy^2 + b' dx dy in six operations and alpha = opacity exp2(-that) without the scaling
-      // multiply of expf; the depth rides in the colour record's spare lane (one packed accumulate for the four channels)
-      sb.s1[tid] = make_float4(r1.x * (0.5f * GSL_LOG2E), r1.y * GSL_LOG2E, r1.z * (0.5f * GSL_LOG2E), r1.w);
-      if (RGB && MODE == 0) sb.s2[tid] = make_float4(r2.x, r2.y, r2.z, r0.z);
+      // multiply of expf.  Laid out for the trip's LDS reads (round 4; the LDS array was 47 % busy, profiles/r04_*):
+      //   s0 = (x, y, a', b')   s1 = (c', opacity, r, g)   s2 = (b, depth, r_cull, -)      [colour modes]
+      //   s0 = (x, y, a', b')   s1 = (c', opacity, depth, r_cull)                          [depth only]
+      // two 16-byte reads and one 8-byte read per candidate (10 LDS cycles) instead of 8 + 4 + 12 + 16 bytes (16 cycles: a
+      // 12-byte read costs 8)
+      const float ca = r1.x * (0.5f * GSL_LOG2E), cb = r1.y * GSL_LOG2E, cc = r1.z * (0.5f * GSL_LOG2E);
+      sb.s0[tid] = make_float4(r0.x, r0.y, ca, cb);
+      if (RGB) {
+        sb.s1[tid] = make_float4(cc, r0.w, r2.x, r2.y);
+        sb.s2[tid] = make_float4(r2.z, r0.z, r1.w, 0.f);
+      } else {
+        sb.s1[tid] = make_float4(cc, r0.w, r0.z, r1.w);
+      }
     } else {
       // every slot holds finite numbers: a lane without a candidate reads SOME slot in the straight-line trip and
       // multiplies what it finds by an exact zero (stale LDS bits can be NaN)
       sb.s0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-      sb.s1[tid] = make_float4(0.f, 0.f, 0.f, -1.f);
-      if (RGB && MODE == 0) sb.s2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (RGB) {
+        sb.s1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sb.s2[tid] = make_float4(0.f, 0.f, -1.f, 0.f);
+      } else {
+        sb.s1[tid] = make_float4(0.f, 0.f, 0.f, -1.f);
+      }
     }
     int n = compact_quadrants<4>(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
     for (int c = 0; c < n; c += 64) {
@@ -187,7 +200,7 @@ __device__ __forceinline__ void praster_walk(
       if (e < n) {
         const unsigned off = sb.qlist[wv][e];  // (byte offset of the record: slot x 16)
         float4 a0 = rec_at(sb.s0, off);
-        float r = rec_at(sb.s1, off).w;
+        float r = RGB ? rec_at(sb.s2, off).z : rec_at(sb.s1, off).w;
         box_range(a0.x - ((float)qx + 0.5f), r, lox, hix);
         box_range(a0.y - ((float)qy + 0.5f), r, loy, hiy);
       }
@@ -221,13 +234,13 @@ __device__ __forceinline__ void praster_walk(
           const bool two = b1 != 0u;
           const unsigned t0 = ql[ffbl_raw(b0)] & 0xFF0u;  // byte offsets (masked: a lane without a candidate reads
           const unsigned t1 = ql[ffbl_raw(b1)] & 0xFF0u;  // whatever sits in front of the chunk's list)
-          float4 p0 = rec_at(sb.s0, t0), p1 = rec_at(sb.s1, t0);
+          float4 p0 = rec_at(sb.s0, t0), p1 = rec_at(sb.s1, t0);  // (x, y, a', b'), (c', opacity, r | depth, g | r_cull)
           float4 u0 = rec_at(sb.s0, t1), u1 = rec_at(sb.s1, t1);
           float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
-          float sg0 = fmaf(p1.y * dx0, dy0, fmaf(p1.x * dx0, dx0, p1.z * dy0 * dy0));  // log2(e) sigma (see the staging)
-          float sg1 = fmaf(u1.y * dx1, dy1, fmaf(u1.x * dx1, dx1, u1.z * dy1 * dy1));
-          float al0 = fminf(GSL_ALPHA_MAX, p0.w * __builtin_amdgcn_exp2f(-sg0));
-          float al1 = fminf(GSL_ALPHA_MAX, u0.w * __builtin_amdgcn_exp2f(-sg1));
+          float sg0 = fmaf(p0.w * dx0, dy0, fmaf(p0.z * dx0, dx0, p1.x * dy0 * dy0));  // log2(e) sigma (see the staging)
+          float sg1 = fmaf(u0.w * dx1, dy1, fmaf(u0.z * dx1, dx1, u1.x * dy1 * dy1));
+          float al0 = fminf(GSL_ALPHA_MAX, p1.y * __builtin_amdgcn_exp2f(-sg0));
+          float al1 = fminf(GSL_ALPHA_MAX, u1.y * __builtin_amdgcn_exp2f(-sg1));
           const bool ok0 = act && sg0 >= 0.f && al0 >= GSL_ALPHA_MIN;
           const bool ok1 = two && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN;
           if (MODE == 1) {
@@ -247,14 +260,15 @@ __device__ __forceinline__ void praster_walk(
           const float vis1 = stop1 ? 0.f : a1 * T1;
           T = stop1 ? T1 : nT1;
           if (RGB) {
-            float4 q20 = rec_at(sb.s2, t0), q21 = rec_at(sb.s2, t1);  // (r, g, b, depth)
-            pix[0] += q20.x * vis0; pix[1] += q20.y * vis0; pix[2] += q20.z * vis0;
-            if (DEPTH) pix[D - 1] += q20.w * vis0;
-            pix[0] += q21.x * vis1; pix[1] += q21.y * vis1; pix[2] += q21.z * vis1;
-            if (DEPTH) pix[D - 1] += q21.w * vis1;
+            const float2 q20 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sb.s2) + t0);  // (b, depth)
+            const float2 q21 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sb.s2) + t1);
+            pix[0] += p1.z * vis0; pix[1] += p1.w * vis0; pix[2] += q20.x * vis0;
+            if (DEPTH) pix[D - 1] += q20.y * vis0;
+            pix[0] += u1.z * vis1; pix[1] += u1.w * vis1; pix[2] += q21.x * vis1;
+            if (DEPTH) pix[D - 1] += q21.y * vis1;
           } else if (DEPTH) {
-            pix[D - 1] += p0.z * vis0;
-            pix[D - 1] += u0.z * vis1;
+            pix[D - 1] += p1.z * vis0;
+            pix[D - 1] += u1.z * vis1;
           }
           // composited <=> alpha >= 1/255 and the pixel did not stop on this entry (alpha T > 0 then: T > 1e-4); as mask
           // logic on the compare results already there, not as two more compares of vis
@@ -331,7 +345,7 @@ template <> struct FwdListPtr<3> { typedef const int32_t* type; };
 
 // long_min > 0: tiles whose list is longer than long_min entries are left to the long-list kernels below.
 template <int D, bool ED, int SORT>
-__global__ __launch_bounds__(256) void k_praster_fwd(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SORT == 3 ? 4 : 6))) void k_praster_fwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
     int tile_w, int ty0, typename FwdListPtr<SORT>::type tile_offsets, typename FwdListPtr<SORT>::type flatten_ids,
     long long capacity, float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,

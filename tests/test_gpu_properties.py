@@ -50,8 +50,8 @@ def test_properties_at_full_size(N, W, H, staging):
     tile_of = torch.repeat_interleave(torch.arange(ctx.n_tiles, device=dev), offs[1:] - offs[:-1])
     depth_bits = ctx.Q0[:, 2].contiguous().view(torch.int32).long()[ids]
     # (random-order input: the context stores the Gaussians in tile order; the sort key's id is the CALLER's index)
-    assert ctx.order_ids is not None, "1 M+ randomly ordered Gaussians are placed in tile order"
-    key = (depth_bits << 32) | ctx.order_ids.long()[ids]
+    assert (ctx.order_ids is not None) == (N <= ctx.REORDER_MAX_N), "1 M randomly ordered Gaussians are placed in tile order"
+    key = (depth_bits << 32) | (ctx.order_ids.long()[ids] if ctx.order_ids is not None else ids)
     same_tile = tile_of[1:] == tile_of[:-1]
     assert bool((key[1:][same_tile] > key[:-1][same_tile]).all())
     # ---- idempotence, and binned == two-pass lists / image
