@@ -134,8 +134,11 @@ class RenderContext:
         self.capacity = max(int(capacity), 1)
         self.keys = torch.zeros(self.capacity, dtype=torch.int64, device=self.device)
         self.flatten_ids = torch.zeros(self.capacity, dtype=torch.int32, device=self.device)
-        # per tile and quadrant: the list entries its pixels composited (written by the forward, read by the backward)
-        self.hits = torch.zeros(4 * self.capacity, dtype=torch.int32, device=self.device)
+        # per tile and quadrant: the list entries its pixels composited (written by the forward, read by the backward).
+        # A hit word keeps the list index in 28 bits: beyond 2^28 intersections the forward records nothing and the backward
+        # tests the blocks geometrically (same result; the C side refuses hit lists at that size)
+        self.hits = (torch.zeros(4 * self.capacity, dtype=torch.int32, device=self.device)
+                     if self.capacity < (1 << 28) else None)
         if self.deterministic:
             self.vrow = torch.zeros(self.capacity, 16, dtype=torch.float32, device=self.device)
 
@@ -407,9 +410,9 @@ class RenderContext:
                                             ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                             ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
                                             ptr(self.ws) if self.bins is not None else None,
-                                            ptr(self.hits) if self.record_hits else None,
-                                            ptr(self.hit_counts) if self.record_hits else None, self.long_min,
-                                            ptr(self.bins) if sif else None, self.bin_cap if sif else 0,
+                                            ptr(self.hits) if (self.record_hits and self.hits is not None) else None,
+                                            ptr(self.hit_counts) if (self.record_hits and self.hits is not None) else None,
+                                            self.long_min, ptr(self.bins) if sif else None, self.bin_cap if sif else 0,
                                             ptr(self.n_is) if sif else None, ptr(self.flags) if sif else None,
                                             ptr(self.storage_of) if sif else None, current_stream()),
               "gsl_fused_raster_fwd")
@@ -421,7 +424,7 @@ class RenderContext:
                                                self.H, self.tw, self.th, self.ty0, self.ty1, ptr(self.offs),
                                                ptr(self.flatten_ids), self.capacity, ptr(self.render), ptr(self.alphas),
                                                ptr(self.last_ids), self.row0, self.row1, ptr(self.Qh),
-                                               ptr(self.hits) if self.record_hits else None,
+                                               ptr(self.hits) if (self.record_hits and self.hits is not None) else None,
                                                self.long_min, ptr(self.long_ws), self.long_ws_bytes, self.max_seg,
                                                int(self.bins is not None), current_stream()), "gsl_long_raster_fwd")
 

@@ -226,7 +226,11 @@ __device__ __forceinline__ void qraster_bwd_body(
       if (nib) {
         sb.id[slot] = gid;
         sb.s0[slot] = r0;
-        sb.s1[slot] = make_float4(r1.x, r1.y, r1.z, __int_as_float((int)idx));
+        // the conic as the FORWARD stages it (times log2 e, diagonal halved: raster_px.hip praster_walk), so that a trip
+        // evaluates alpha with the forward's very operations and both sides take the same alpha >= 1/255 decision for
+        // every (pixel, entry) pair; the flush scales back
+        sb.s1[slot] = make_float4(r1.x * (0.5f * GSL_LOG2E), r1.y * GSL_LOG2E, r1.z * (0.5f * GSL_LOG2E),
+                                  __int_as_float((int)idx));
         if (RGB && CG == D) sb.s2[slot] = r2;
         sb.posn[slot] = pack;
       }
@@ -263,10 +267,8 @@ __device__ __forceinline__ void qraster_bwd_body(
         q0 = sb.s0[t_cur];
         q1 = sb.s1[t_cur];
         float dx = c0.x - px, dy = c0.y - py;
-        float gx = c1.x * dx + c1.y * dy;
-        float gy = c1.y * dx + c1.z * dy;
-        float sigma = 0.5f * (dx * gx + dy * gy);
-        float vis = __expf(-sigma);
+        float sigma = fmaf(c1.y * dx, dy, fmaf(c1.x * dx, dx, c1.z * dy * dy));  // log2(e) sigma, the forward's expression
+        float vis = __builtin_amdgcn_exp2f(-sigma);
         float opv = c0.w * vis;
         float alpha = fminf(GSL_ALPHA_MAX, opv);
         unsigned long long validm = __ballot(__float_as_int(c1.w) <= bin_final) & __ballot(sigma >= 0.f) &
@@ -362,6 +364,7 @@ __device__ __forceinline__ void qraster_bwd_body(
           float Sxy = X * (Y * S - mo[u][2]) - Y * mo[u][1] + mo[u][4];
           float Syy = Y * (Y * S - 2.f * mo[u][2]) + mo[u][5];
           float no = -r0.w;
+          r1.x *= 2.f / GSL_LOG2E; r1.y *= 1.f / GSL_LOG2E; r1.z *= 2.f / GSL_LOG2E;  // (staged times log2 e: see the gather)
           row[0] = no * (r1.x * Sx + r1.y * Sy);
           row[1] = no * (r1.y * Sx + r1.z * Sy);
           row[2] = 0.5f * no * Sxx;
@@ -503,6 +506,9 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
 #pragma unroll
           for (int k = 0; k < D; ++k) dot += vc[k] * cc[k];
           Bp_init += dot;
+          // as k_long_combine: a pixel that stopped INSIDE this segment composited nothing behind it, whatever the later
+          // segments' own restart products say (their T0 may round to the other side of 1e-4)
+          if (t8[u] < 0.f) stop = true;
         }
       }
     }

@@ -76,8 +76,10 @@ class _FusedRasterization(torch.autograd.Function):
         alphas = torch.zeros(H, W, 1, dtype=f32, device=dev) if (ty0, ty1) != (0, th) else \
             torch.empty(H, W, 1, dtype=f32, device=dev)
         last_ids = torch.zeros(H, W, dtype=i32, device=dev)
-        hits = torch.empty(4 * cap, dtype=torch.int32, device=dev)  # per tile and quadrant: the entries it composited
-        hit_counts = torch.empty(4 * n_tiles + 1, dtype=i32, device=dev)
+        # per tile and quadrant: the entries it composited (a hit word holds the list index in 28 bits: none beyond that,
+        # the backward then tests the blocks geometrically)
+        hits = torch.empty(4 * cap, dtype=torch.int32, device=dev) if cap < (1 << 28) else None
+        hit_counts = torch.empty(4 * n_tiles + 1, dtype=i32, device=dev) if hits is not None else None
         check(lib.gsl_fused_raster_fwd(ptr(Q0), ptr(Q1), ptr(Q2), D, int(ed), W, H, tw, th, ty0, ty1, ptr(offs),
                                        ptr(flatten_ids) if n_isects else None, n_isects, ptr(render), ptr(alphas),
                                        ptr(last_ids), 0, H, None, None, ptr(hits), ptr(hit_counts), 0, None, 0, None, None,
