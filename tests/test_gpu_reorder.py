@@ -179,3 +179,52 @@ def test_autograd_through_a_placed_context_returns_gradients_in_the_callers_orde
         grads.append([t.grad.clone() for t in ins] + [Vg.grad.clone()])
     for a, b in zip(*grads):  # (+1e-7: v_quats of isotropic splats is cancellation noise of ~1e-8)
         assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7
+
+
+def test_zero_colour_gradients_are_not_stored_and_stale_ones_are_cleared():
+    """gsl_fused_project_bwd(..., v_colors_state): under a depth-only upstream gradient (GsplatLoc's loss,
+    /root/reference/src/my_gsplat/gs_trainer_total.py:111-123) no Gaussian has a colour gradient and the 48 bytes of zeros per
+    Gaussian are not stored while the context's buffer is known to be zero.  The state must follow the buffer: a backward
+    WITH a colour gradient writes it and marks the buffer dirty; the next depth-only backward must clear those values again."""
+    from gsplatloc_amd.context import RenderContext
+    W, H, N = 200, 160, 20000
+    means, quats, scales, opac, sh, K = _wall(N, W, H, 1.1, seed=13)
+    ins = [t.to(DEV) for t in (means, quats, scales, opac, sh)]
+    K = K.to(DEV).contiguous()
+    V = torch.linalg.inv(small_pose(0.4, 0.01, dtype=torch.float32)).to(DEV).contiguous()
+    gen = torch.Generator().manual_seed(2)
+    v_depth = torch.zeros(H, W, 4)
+    v_depth[..., 3] = torch.randn(H, W, generator=gen)
+    v_rgb = torch.randn(H, W, 4, generator=gen)
+    v_depth, v_rgb = v_depth.to(DEV), v_rgb.to(DEV)
+    va = torch.zeros(H, W, 1, device=DEV)
+    rc = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, reorder=False)
+    rc.calibrate(*ins, V, K)
+    ref = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, reorder=False)
+    ref.calibrate(*ins, V, K)
+    ref.vc_state = None  # the reference context always stores every colour gradient
+
+    def run(ctx, v):
+        ctx.forward(*ins, V, K)
+        g = ctx.backward(v, va)
+        torch.cuda.synchronize()
+        return {k: t.clone() for k, t in g.items()}
+
+    assert int(rc.vc_state) == 1
+    rc.v_colors.fill_(7.0)          # what a skipped store would leave behind if the state were wrong ...
+    rc.vc_state.zero_()             # ... so tell the kernel the buffer is of unknown content
+    a = run(rc, v_depth)
+    assert float(a["colors"].abs().max()) == 0.0 and int(rc.vc_state) == 1   # everything stored once, then known zero
+    rc.v_colors[5] = 3.0            # (a skipped store leaves this: proves the zero stores are really skipped now)
+    b = run(rc, v_depth)
+    assert float(b["colors"][5].abs().max()) == 3.0 and int(rc.vc_state) == 1
+    rc.v_colors[5] = 0.0
+    c, c_ref = run(rc, v_rgb), run(ref, v_rgb)
+    assert float(c["colors"].abs().max()) > 0 and int(rc.vc_state) == 0      # dirty: a real colour gradient was written
+    assert torch.equal(c["colors"] != 0, c_ref["colors"] != 0)
+    assert float((c["colors"] - c_ref["colors"]).abs().max()) <= 2e-4 * float(c_ref["colors"].abs().max())
+    d, d_ref = run(rc, v_depth), run(ref, v_depth)
+    assert float(d["colors"].abs().max()) == 0.0, "stale colour gradients survived a depth-only backward"
+    assert int(rc.vc_state) == 1
+    for k in ("means", "scales", "opacities", "viewmat"):
+        assert float((d[k] - d_ref[k]).abs().max()) <= 2e-4 * float(d_ref[k].abs().max()) + 1e-12, k
