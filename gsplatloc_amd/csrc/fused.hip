@@ -903,12 +903,12 @@ __global__ __launch_bounds__(256) void k_freduce_rows(const float* __restrict__ 
         threadIdx.x < 15 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
 }
 
-__global__ __launch_bounds__(256) void k_freduce_viewmat(const float* __restrict__ partials, int nb,
-                                                        const float* __restrict__ V, const float* __restrict__ Kmat,
-                                                        float* __restrict__ v_viewmat, int32_t* __restrict__ vc_state) {
-  __shared__ float red[4][15];
+__global__ __launch_bounds__(1024) void k_freduce_viewmat(const float* __restrict__ partials, int nb,
+                                                         const float* __restrict__ V, const float* __restrict__ Kmat,
+                                                         float* __restrict__ v_viewmat, int32_t* __restrict__ vc_state) {
+  __shared__ float red[16][15];
   __shared__ float tot[15];
-  float v = reduce_viewmat_rows(partials, nb, V, Kmat, red, tot);
+  float v = reduce_viewmat_rows_wide(partials, nb, V, Kmat, red, tot);
   if (threadIdx.x < 16) v_viewmat[threadIdx.x] = v;
   // (see k_fproject_bwd) 2: a real colour gradient was written in the launch before this one -> unknown; otherwise every
   // Gaussian's slot holds zeros now
@@ -1151,9 +1151,9 @@ extern "C" int gsl_fused_project_bwd(const float* means, const float* quats, con
     if (grid > 8192) {  // two stages (fixed order either way)
       float* stage = partials + (size_t)grid * 16;
       hipLaunchKernelGGL(gsl::k_freduce_rows, dim3(GSL_VM_STAGE_ROWS), dim3(256), 0, st, partials, grid, stage);
-      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, stage, GSL_VM_STAGE_ROWS, viewmat, K, v_viewmat, vcs);
+      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(1024), 0, st, stage, GSL_VM_STAGE_ROWS, viewmat, K, v_viewmat, vcs);
     } else {
-      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(256), 0, st, partials, grid, viewmat, K, v_viewmat, vcs);
+      hipLaunchKernelGGL(gsl::k_freduce_viewmat, dim3(1), dim3(1024), 0, st, partials, grid, viewmat, K, v_viewmat, vcs);
     }
     GSL_CHECK_LAUNCH();
   }

@@ -185,6 +185,27 @@ __device__ __forceinline__ void cam_inverse(const Cam& cam, M3& Ri, float cp[3])
   for (int k = 0; k < 3; ++k) cp[k] = -(Ri(k, 0) * cam.t[0] + Ri(k, 1) * cam.t[1] + Ri(k, 2) * cam.t[2]);
 }
 
+// Thread t < 16 of a workgroup: entry t of v_viewmat from the 15 summed rows [v_R 9 | v_t 3 | v_campos 3] (the SH view
+// direction chained through the camera position, campos = -R^-1 t; row 3 = 0: that row is constant).
+__device__ __forceinline__ float viewmat_from_totals(const float* tot, const float* __restrict__ V,
+                                                     const float* __restrict__ Kmat) {
+  float v = 0.f;
+  if (threadIdx.x < 16) {
+    int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+    if (r < 3) {
+      Cam cam = load_cam(V, Kmat);
+      M3 Ri;
+      float cp[3];
+      cam_inverse(cam, Ri, cp);
+      // w = R^-T v_campos
+      float w = Ri(0, r) * tot[12] + Ri(1, r) * tot[13] + Ri(2, r) * tot[14];
+      if (c < 3) v = tot[r * 3 + c] - w * cp[c];
+      else v = tot[9 + r] - w;
+    }
+  }
+  return v;
+}
+
 // The pose gradient leaves the projection backward as one row of 15 sums per workgroup
 // ([v_R 9 | v_t 3 | v_campos 3], 16 floats apart).  Fixed-order sum of the rows by a 256-thread workgroup, chain of
 // the SH view direction through the camera position (campos = -R^-1 t): thread t < 16 returns v_viewmat[t]
@@ -223,21 +244,50 @@ __device__ __forceinline__ float reduce_viewmat_rows(const float* __restrict__ p
   __syncthreads();
   if (threadIdx.x < 15) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
   __syncthreads();
-  float v = 0.f;
-  if (threadIdx.x < 16) {
-    int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-    if (r < 3) {
-      Cam cam = load_cam(V, Kmat);
-      M3 Ri;
-      float cp[3];
-      cam_inverse(cam, Ri, cp);
-      // w = R^-T v_campos
-      float w = Ri(0, r) * tot[12] + Ri(1, r) * tot[13] + Ri(2, r) * tot[14];
-      if (c < 3) v = tot[r * 3 + c] - w * cp[c];
-      else v = tot[9 + r] - w;
-    }
+  return viewmat_from_totals(tot, V, Kmat);
+}
+
+// The same reduction by a 1024-thread workgroup (k_freduce_viewmat: 3 907 rows at 1 M Gaussians; with 256 threads the
+// launch was 9.5 us of dependent L2 round trips, 15 rounds of 4 loads in flight per thread).  Its own fixed order:
+// thread (row mod 256, quarter), four rows in flight, lanes of equal quarter folded, the 16 waves summed in wave order.
+__device__ __forceinline__ float reduce_viewmat_rows_wide(const float* __restrict__ partials, int nb,
+                                                          const float* __restrict__ V, const float* __restrict__ Kmat,
+                                                          float (*red)[15], float* tot) {
+  int q = threadIdx.x & 3;
+  const float4* rows = reinterpret_cast<const float4*>(partials) + q;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  int b = threadIdx.x >> 2;
+  for (; b + 768 < nb; b += 1024) {
+    float4 x0 = rows[(size_t)b * 4], x1 = rows[(size_t)(b + 256) * 4], x2 = rows[(size_t)(b + 512) * 4],
+           x3 = rows[(size_t)(b + 768) * 4];
+    a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+    a1.x += x1.x; a1.y += x1.y; a1.z += x1.z; a1.w += x1.w;
+    a2.x += x2.x; a2.y += x2.y; a2.z += x2.z; a2.w += x2.w;
+    a3.x += x3.x; a3.y += x3.y; a3.z += x3.z; a3.w += x3.w;
   }
-  return v;
+  for (; b < nb; b += 256) {
+    float4 x0 = rows[(size_t)b * 4];
+    a0.x += x0.x; a0.y += x0.y; a0.z += x0.z; a0.w += x0.w;
+  }
+  float v4[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                 (a0.w + a1.w) + (a2.w + a3.w)};
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = v4[c];
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+    if (lane < 4 && 4 * q + c < 15) red[wv][4 * q + c] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 15) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][threadIdx.x];
+    tot[threadIdx.x] = s;
+  }
+  __syncthreads();
+  return viewmat_from_totals(tot, V, Kmat);
 }
 
 // ---- tiny-splat backward, pass 2 (csrc/raster_px.hip has pass 1 and the story) ---------------------------------------
