@@ -228,3 +228,41 @@ def test_zero_colour_gradients_are_not_stored_and_stale_ones_are_cleared():
     assert int(rc.vc_state) == 1
     for k in ("means", "scales", "opacities", "viewmat"):
         assert float((d[k] - d_ref[k]).abs().max()) <= 2e-4 * float(d_ref[k].abs().max()) + 1e-12, k
+
+
+def test_strips_of_placed_gaussians_reproduce_the_full_frame():
+    """The N > 1 path of bench.py / GraphTracker on one GPU: two tile-row strips, each keeping only the Gaussians within its
+    guard band AND placing them in tile order, against the full frame rendered from the caller's (random) order: the
+    strips' pixels bit-identical, the two pose gradients adding up to the full frame's."""
+    from gsplatloc_amd.context import RenderContext
+    from gsplatloc_amd.parallel import gaussians_for_strip
+    W, H, N = 320, 240, 60000
+    means, quats, scales, opac, sh, K = _wall(N, W, H, 1.2, seed=17)
+    ins = [t.to(DEV) for t in (means, quats, scales, opac, sh)]
+    K = K.to(DEV).contiguous()
+    V = torch.linalg.inv(small_pose(0.5, 0.015, dtype=torch.float32)).to(DEV).contiguous()
+    gen = torch.Generator().manual_seed(3)
+    v = torch.randn(H, W, 4, generator=gen).to(DEV)
+    va = torch.randn(H, W, 1, generator=gen).to(DEV)
+    full = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, reorder=False, full_grads=False)
+    full.calibrate(*ins, V, K)
+    full.forward(*ins, V, K)
+    g_full = full.backward(v, va, full=False)["viewmat"].clone()
+    torch.cuda.synchronize()
+    th = (H + 15) // 16
+    total = torch.zeros_like(g_full)
+    for rows in ((0, 6), (6, th)):
+        idx = gaussians_for_strip(full.Q0[:, 0:2], full.radii, rows)
+        loc = [t[idx].contiguous() for t in ins]
+        rc = RenderContext(int(idx.numel()), W, H, "RGB+ED", sh_degree=1, K_sh=4, device=DEV, tile_rows=rows, reorder=True,
+                           full_grads=False)
+        rc.calibrate(*loc, V, K)
+        assert rc.order_ids is not None
+        rc.forward(*loc, V, K)
+        g = rc.backward(v, va, full=False)["viewmat"].clone()
+        torch.cuda.synchronize()
+        rc.check_capacity()
+        r0, r1 = rows[0] * 16, min(rows[1] * 16, H)
+        assert torch.equal(rc.render[r0:r1], full.render[r0:r1]) and torch.equal(rc.alphas[r0:r1], full.alphas[r0:r1])
+        total += g
+    assert float((total - g_full).abs().max()) <= 2e-5 * float(g_full.abs().max())
