@@ -648,16 +648,19 @@ def main():
         # once per frame (untimed): balance strips on a full binning pass, keep the Gaussians that can reach
         # this rank's strip (1-tile guard band), the rest never touch its pixels
         from gsplatloc_amd.parallel import gaussians_for_strip
-        cal = C.RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
+        # (reorder=False: cal.Q0 / cal.radii index the Gaussians below, so they must be in the CALLER's order -- a placed
+        # calibration context silently selects the wrong Gaussians; the intersection count of the strip is asserted further down)
+        cal = C.RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False, reorder=False)
         cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
         rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank]
-        idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
+        strip_isects_expected = int(cal.offs[rows[1] * cal.tw] - cal.offs[rows[0] * cal.tw])
+        idx = cal.gaussians_reaching(rows)
         # the guard band is checked, not assumed (GraphTracker does the same at every poll, where the pose
         # moves): no Gaussian outside the kept set may reach the strip at the pose the timed steps render
         kept = torch.zeros(N, dtype=torch.bool, device=dev)
         kept[idx] = True
         reach = torch.zeros(N, dtype=torch.bool, device=dev)
-        reach[gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows, guard_tiles=0)] = True
+        reach[cal.gaussians_reaching(rows, guard_tiles=0)] = True
         band_violations = int((reach & ~kept).sum())
         assert band_violations == 0, f"{band_violations} Gaussians outside the kept set reach strip {rows}"
         for k in sc:
@@ -669,6 +672,8 @@ def main():
                           staging=args.staging)
     n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
     trace(f"calibrated, {n_isects} intersections")
+    if world > 1:  # the strip's lists hold exactly the full frame's entries of its tile rows
+        assert n_isects == strip_isects_expected, (rank, rows, n_isects, strip_isects_expected)
     from gsplatloc_amd.synthetic import depth_upstream
     v_render = depth_upstream(H, W, 1).to(dev)  # (seed 1 of the parity statement's three: tests/test_gpu_configs.py)
     v_alphas = torch.zeros(H, W, 1, device=dev)

@@ -212,6 +212,16 @@ class RenderContext:
         pl = self._placed
         return pl[0], pl[1], pl[2], pl[3], (pl[4] if len(pl) > 4 else colors)
 
+    def gaussians_reaching(self, rows: Tuple[int, int], guard_tiles: int = 1) -> Tensor:
+        """Indices -- in the CALLER's order, whatever the placement -- of the Gaussians whose splat (centre +- radius of the
+        last projection) touches tile rows [rows[0] - guard, rows[1] + guard): what a strip keeps (parallel.py).  Use this,
+        not gaussians_for_strip(rc.Q0, rc.radii, ...) on a context that may have placed its Gaussians: Q0 and radii are in
+        STORAGE order then, and indexing the caller's arrays with storage slots silently selects other Gaussians (round 4:
+        a strip-scaling estimate that rendered half of every strip's intersections and looked super-linear)."""
+        from .parallel import gaussians_for_strip
+        idx = gaussians_for_strip(self.Q0[:, 0:2], self.radii, rows, guard_tiles=guard_tiles)
+        return idx if self.order_ids is None else self.order_ids.long()[idx]
+
     def grads_in_input_order(self, grads: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """backward()'s per-Gaussian gradients in the CALLER's order (new tensors; `viewmat` passed through)."""
         if self.storage_of is None:

@@ -100,7 +100,24 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
 // one interleaved array of 64-byte rows made the random-order forward 10 % faster and projection / binning slower,
 // no net gain; a workgroup -> tile map that gives each XCD one contiguous span of tiles changed nothing.)
 #define GSL_Q(arr, g) (arr)[(g)]
-#define GSL_TILE_OF_BLOCK() blockIdx.x
+// Workgroup -> work item.  Workgroups go to the eight XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has
+// its own 4 MiB L2.  With GSL_XCD_SPANS the items (tiles, in raster order) are dealt so that XCD x gets ONE contiguous
+// span of them: with the Gaussians stored in tile order (context.py:_choose_placement) the records an XCD gathers are
+// then one eighth of the frame's instead of all of them.  (Round 2 tried the same map on randomly ordered records: no
+// locality to keep, no effect.)
+#ifndef GSL_XCD_SPANS
+#define GSL_XCD_SPANS 0
+#endif
+__device__ __forceinline__ int xcd_span_item(int b, int n) {
+#if GSL_XCD_SPANS
+  const int x = b & 7, k = b >> 3, q = n >> 3, r = n & 7;
+  return x * q + min(x, r) + k;
+#else
+  (void)n;
+  return b;
+#endif
+}
+#define GSL_TILE_OF_BLOCK() gsl::xcd_span_item((int)blockIdx.x, (int)gridDim.x)
 
 // ---- fp16-staged records (workload X, "fp16 compositing": BASELINE.json configs[4]) --------------------
 // One 32-byte record per Gaussian for the compositing kernels instead of three 16-byte ones: the centre stays float32

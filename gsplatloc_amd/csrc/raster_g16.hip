@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
   // (a forward that sorted its own bins could not clear the tile counters, raster_px.hip k_praster_fwd SORT: the first
   // launch of the backward does, one lane per tile)
   if (!LONG && (CG == 1 || D == 3) && clear_counts && (blockIdx.x & 3) == 0 && threadIdx.x == 0) {
-    clear_counts[ty0 * tile_w + (blockIdx.x >> 2)] = 0;
+    clear_counts[ty0 * tile_w + (blockIdx.x >> 2)] = 0;  // (any one-to-one map of workgroups to tiles does for clearing)
     if (blockIdx.x == 0 && clear_state) *clear_state = 0;
   }
   // rgb_flag (may be NULL; D = 4 only): raised by the depth-only kernel when it leaves a quadrant to the full-colour
@@ -423,7 +423,10 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
   // workgroup instead of reading its 64 pixels' upstream gradient to find out that it has nothing to do (GsplatLoc's
   // loss: always).  A stale raised flag (a second backward after the same forward) only costs that reading.
   if (D == 4 && CG == D && rgb_flag && *rgb_flag == 0) return;
-  const int quad = blockIdx.x & 3, item = blockIdx.x >> 2;
+  // (LONG: items are (tile, segment) slots; otherwise the (tile, quadrant) pairs are dealt to the XCDs in contiguous
+  // spans: gsloc_common.h)
+  const int wi = LONG ? (int)blockIdx.x : xcd_span_item((int)blockIdx.x, (int)gridDim.x);
+  const int quad = wi & 3, item = wi >> 2;
   int tile, sgm = 0, gseg = 0;
   if (LONG) {
     gseg = item;

@@ -146,7 +146,11 @@ class GraphTracker:
         n = int(idx.numel())
         if self.rc.N != n:
             self.rc = self._make_rc(n)
-        self.rc.calibrate(*self._active, self.viewmat, self.K, headroom=self.headroom)
+        got = self.rc.calibrate(*self._active, self.viewmat, self.K, headroom=self.headroom)
+        # the kept set must reproduce the full projection's lists of the rendered rows (the check context just binned all N
+        # Gaussians over exactly those rows at this pose)
+        want = int(self._check.n_is.item())
+        assert got == want or want == 0, f"strip {self.render_rows}: {got} intersections from the kept set, {want} from all"
 
     def _band_violations(self) -> int:
         """Gaussians outside the kept set whose splat reaches the rendered rows at the current pose (0 = the band held)."""

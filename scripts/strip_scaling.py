@@ -20,7 +20,7 @@ K = sc["K"].contiguous()
 g = torch.Generator().manual_seed(1)
 v = torch.zeros(H, W, 4); v[..., 3] = torch.randn(H, W, generator=g); v = v.to(dev)
 va = torch.zeros(H, W, 1, device=dev)
-cal = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False)
+cal = RenderContext(N, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, full_grads=False, reorder=False)  # (indexes sc[...])
 cal.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
 base = None
 for world in (1, 2, 4, 8):
@@ -28,7 +28,7 @@ for world in (1, 2, 4, 8):
     for rank in range(world):
         rows = strip_rows(cal.offs, cal.tw, cal.th, world)[rank] if world > 1 else (0, cal.th)
         if world > 1:
-            idx = gaussians_for_strip(cal.Q0[:, 0:2], cal.radii, rows)
+            idx = cal.gaussians_reaching(rows)
             loc = {k: sc[k][idx].contiguous() for k in ("means", "quats", "scales", "opacities", "sh")}
         else:
             loc = sc
@@ -36,7 +36,10 @@ for world in (1, 2, 4, 8):
         ctx = RenderContext(n, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=True,
                             staging=staging)
         inp = (loc["means"], loc["quats"], loc["scales"], loc["opacities"], loc["sh"], viewmat, K)
-        ctx.calibrate(*inp)
+        n_strip = ctx.calibrate(*inp)
+        if world > 1:
+            want = int(cal.offs[rows[1] * cal.tw] - cal.offs[rows[0] * cal.tw])
+            assert n_strip == want, (rows, n_strip, want)  # the strip's lists = the full frame's entries of its rows
         def step():
             ctx.forward(*inp); ctx.backward(v, va, full=True)
         side = torch.cuda.Stream()
@@ -52,9 +55,9 @@ for world in (1, 2, 4, 8):
         for _ in range(20): gr.replay()
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t) / 20 * 1e3)
-        if rank == world // 2:
+        if rank == world // 2 or world == 2:
             st = time_stages(ctx, inp, v, va, True, steps=10)
-            print(f"   world {world} rank {rank}: rows {rows} n={n} stages " + " ".join(f"{k}={x*1e3:.0f}us" for k, x in st.items()), flush=True)
+            print(f"   world {world} rank {rank}: rows {rows} n={n} isects={int(ctx.n_is.item())} placed={ctx.order_ids is not None} tiny={ctx.tiny} stages " + " ".join(f"{k}={x*1e3:.0f}us" for k, x in st.items()), flush=True)
         del gr, ctx
     worst = max(times)
     base = base or worst

@@ -52,7 +52,7 @@ class FakeContext:
         g = torch.Generator().manual_seed(0)
         self.Q0 = torch.rand(N, 4, generator=g) * torch.tensor([float(width), float(height), 1.0, 1.0])
         self.radii = torch.full((N,), 4, dtype=torch.int32)
-        per_tile = max(1, (2 * N) // self.n_tiles)
+        per_tile = 7  # (a constant: the strip contexts of the N > 1 path must count what the calibration context counted)
         self.offs = torch.arange(self.n_tiles + 1, dtype=torch.int32) * per_tile
         self.v_viewmat = torch.zeros(4, 4)
         self.calls = 0
@@ -77,6 +77,10 @@ class FakeContext:
 
     def _place(self, *a):
         return a
+
+    def gaussians_reaching(self, rows, guard_tiles=1):
+        from gsplatloc_amd.parallel import gaussians_for_strip
+        return gaussians_for_strip(self.Q0[:, 0:2], self.radii, rows, guard_tiles=guard_tiles)
 
     _bin = _raster_fwd = _project
     _raster_bwd = _project_bwd = _project
