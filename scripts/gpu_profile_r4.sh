@@ -23,7 +23,7 @@ B="--no-cpu-baseline --no-tracker --no-variants"
 for wl in R D X; do
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$wl -o st --output-format csv -- python3 bench.py $B --workload $wl --steps 10 --warmup 3 > gpurun_out/prof_$wl.log 2>&1; guard $?
 done
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_trk -o st --output-format csv -- python3 scripts/bench_tracker.py > gpurun_out/prof_trk.log 2>&1; guard $?
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_trk -o st --output-format csv -- python3 scripts/bench_tracker.py S graph > gpurun_out/prof_trk.log 2>&1; guard $?
 P="--no-graph --steps 3 --warmup 1"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch -o f --output-format csv -- python3 bench.py $B $P > gpurun_out/pmc_fetch.log 2>&1; guard $?
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -o w --output-format csv -- python3 bench.py $B $P > gpurun_out/pmc_write.log 2>&1; guard $?
