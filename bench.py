@@ -671,6 +671,14 @@ def main():
     ctx = C.RenderContext(n_local, W, H, "RGB+ED", sh_degree=1, K_sh=4, device=dev, tile_rows=rows, full_grads=full,
                           staging=args.staging)
     n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+    # what a frame pays ONCE, outside the timed steps (a tracker runs hundreds of steps per frame): the measuring pass that
+    # sizes lists and bins, the tile-order placement (a stable sort of N tile indices + five gathers) and the allocations;
+    # timed on a second call, when the allocator is warm
+    torch.cuda.synchronize()
+    t_cal = time.perf_counter()
+    n_isects = ctx.calibrate(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["sh"], viewmat, K)
+    torch.cuda.synchronize()
+    calibrate_ms = (time.perf_counter() - t_cal) * 1e3
     trace(f"calibrated, {n_isects} intersections")
     if world > 1:  # the strip's lists hold exactly the full frame's entries of its tile rows
         assert n_isects == strip_isects_expected, (rank, rows, n_isects, strip_isects_expected)
@@ -813,6 +821,7 @@ def main():
                           if graph is not None else "eager",
                 "backward": backward_name(ctx),
                 "gaussian_placement": placement_name(ctx),
+                "per_frame_calibrate_ms": calibrate_ms,  # (once per frame, NOT in ms_per_step: see the comment at its timing)
                 "binning": ("keys written into per-tile bins by the projection kernel (sizes from calibrate()), "
                             "register sort per tile" if getattr(ctx, "bins", None) is not None
                             else "count, scan, scatter, register sort per tile"),
