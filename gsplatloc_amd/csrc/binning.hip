@@ -385,6 +385,11 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
 // tiles, the last one also the total; a tile that outgrew its bin keeps bin_cap entries and raises flags[1] (its size
 // goes to flags[2]).  The separate single-workgroup scan launch disappears; the counters are cleared later by the
 // compositing forward (every workgroup may still be reading them here).
+// MAXLK = 4 / 5: the longest list one wave sorts in registers is 1024 / 2048 keys; longer ones go to the workgroup's LDS
+// sort below.  The 32-keys-per-lane network is what sets the kernel's register count (141 VGPR once every compare is a
+// ballot: three waves per SIMD, one fewer than a frame of 3 225 tiles needs to be resident at once), so frames whose lists
+// are expected to stay below 1024 keys run the instance without it (gsl_tile_sort_keys).
+template <int MAXLK>
 __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_offsets, int tile_begin,
                                                    int n_strip_tiles, long long capacity,
                                                    uint64_t* __restrict__ keys, int32_t* __restrict__ flatten_ids,
@@ -444,11 +449,11 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
     // sorted keys go to the packed array; in place when that is also the source (every lane has read its keys
     // into registers before any lane writes)
     uint64_t* kout = write_sorted_keys ? keys : nullptr;
-    if (n > 0 && n <= GSL_SORT_WAVE_MAX) {
+    if (n > 0 && n <= (64 << MAXLK)) {
       if (n <= 256) wave_sort_tile<2>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
       else if (n <= 512) wave_sort_tile<3>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
-      else if (n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
-      else wave_sort_tile<5>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
+      else if (MAXLK == 4 || n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
+      else wave_sort_tile<(MAXLK > 4 ? 5 : 4)>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
     }
   }
   // rare: lists too long for one wave, sorted in place by the whole workgroup, one after the other
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
     if (e > capacity) e = capacity;
     int n = (int)max(e - s, (long long)0);
     if (bins && n > bin_cap) n = bin_cap;
-    if (n <= GSL_SORT_WAVE_MAX) continue;
+    if (n <= (64 << MAXLK)) continue;
     if (long_min > 0 && bins && n > long_min) continue;  // sorted by several workgroups: gsl_long_sort
     uint64_t* src = bins ? bins + (size_t)t * (size_t)bin_cap : keys + s;
     __syncthreads();
@@ -806,8 +811,14 @@ extern "C" int gsl_tile_sort_keys(int32_t* tile_offsets, int tile_begin, int n_s
     hipLaunchKernelGGL(gsl::k_tile_sort_wg, dim3(n_strip_tiles), dim3(256), 0, (hipStream_t)stream, tile_offsets,
                        tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
                        write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min, storage_of);
+  else if (mean_list <= 1150 && !(force && force[0] == 'W'))
+    // (capacity carries ~1.3 x head-room: a mean list of <= ~880 keys, whose longest lists stay below 1024 in a frame of
+    // evenly spread splats; a tile that does exceed 1024 takes the workgroup's LDS sort -- slower, never wrong)
+    hipLaunchKernelGGL((gsl::k_tile_sort<4>), dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+                       tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
+                       write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min, storage_of);
   else
-    hipLaunchKernelGGL(gsl::k_tile_sort, dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
+    hipLaunchKernelGGL((gsl::k_tile_sort<5>), dim3((n_strip_tiles + 3) / 4), dim3(256), 0, (hipStream_t)stream, tile_offsets,
                        tile_begin, n_strip_tiles, (long long)capacity, sort_keys, flatten_ids, isect_ids, cam_enc,
                        write_sorted_keys, bins, bin_cap, counts, n_isects, flags, long_min, storage_of);
   GSL_CHECK_LAUNCH();

@@ -12,15 +12,27 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
   hi = (unsigned)__shfl_xor((int)hi, mask, 64);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {  // a <- min, b <- max
-  bool sw = a > b;
-  uint64_t t = sw ? b : a;
-  b = sw ? a : b;
-  a = t;
+// 32-bit select on a 64-bit scalar mask (v_cndmask_b32_e64 with an SGPR pair).  Written with ?: the compiler sends every
+// compare of the network through VCC: v_cmp_lt -> s_nop -> two v_cndmask (VCC) -> v_cmp_gt -> s_nop -> two v_cndmask per
+// compare-exchange -- two compares where one decides both outputs, and a hazard bubble per compare (round 4 found ~640 s_nop
+// and 2 x 480 v_cmp_u64 in one 1024-key sort).  With the outcome as a ballot every compare-exchange is ONE v_cmp into its
+// own SGPR pair and four selects, and consecutive compares do not wait for each other.
+__device__ __forceinline__ unsigned sort_sel(unsigned long long m, unsigned t, unsigned f) {
+  unsigned r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
 }
-__device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, bool keep_min) {
-  bool lt = o < a;
-  return (lt == keep_min) ? o : a;
+__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {  // a <- min, b <- max
+  const unsigned long long sw = __ballot(a > b);
+  const unsigned alo = (unsigned)a, ahi = (unsigned)(a >> 32), blo = (unsigned)b, bhi = (unsigned)(b >> 32);
+  a = ((uint64_t)sort_sel(sw, bhi, ahi) << 32) | sort_sel(sw, blo, alo);
+  b = ((uint64_t)sort_sel(sw, ahi, bhi) << 32) | sort_sel(sw, alo, blo);
+}
+// keep_min_mask: ballot of the lanes that keep the smaller key of (a, partner's o)
+__device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, unsigned long long keep_min_mask) {
+  const unsigned long long take = ~(__ballot(o < a) ^ keep_min_mask);  // take the partner's key where (o < a) == keep_min
+  return ((uint64_t)sort_sel(take, (unsigned)(o >> 32), (unsigned)(a >> 32)) << 32) |
+         sort_sel(take, (unsigned)o, (unsigned)a);
 }
 
 template <int LK>
@@ -47,7 +59,7 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane)
 #pragma unroll 1
   for (int tb = 1; tb <= 6; ++tb) {
     int mask = (1 << tb) - 1;
-    bool keep_min = ((lane >> (tb - 1)) & 1) == 0;
+    const unsigned long long keep_min = __ballot(((lane >> (tb - 1)) & 1) == 0);
 #pragma unroll
     for (int r = 0; r < KPT / 2; ++r) {
       uint64_t o_r = shfl_xor_u64(k[KPT - 1 - r], mask);
@@ -57,7 +69,7 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane)
     }
 #pragma unroll 1
     for (int b = tb - 2; b >= 0; --b) {
-      bool km = ((lane >> b) & 1) == 0;
+      const unsigned long long km = __ballot(((lane >> b) & 1) == 0);
 #pragma unroll
       for (int r = 0; r < KPT; ++r) k[r] = pick(k[r], shfl_xor_u64(k[r], 1 << b), km);
     }

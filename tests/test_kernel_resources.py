@@ -51,10 +51,14 @@ def test_compositing_kernels_keep_their_occupancy():
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_sort_and_projection_kernels_stay_in_registers():
     binning = _resources("binning.hip")
-    sort = [v for k, v in binning.items() if "k_tile_sort" in k]
-    assert len(sort) == 2  # one tile per wave, one tile per workgroup
-    for s in sort:  # 32 keys per lane = 64 registers of keys: no spills, four waves per SIMD, LDS (32 KB, five workgroups per CU: not the limiter) for the long-list path / the workgroup kernel's merge buffers
-        assert s["ScratchSize"] == 0 and s["Occupancy"] >= 4 and s["LDS"] <= 32 * 1024 + 64, s
+    sort = {k: v for k, v in binning.items() if "k_tile_sort" in k}
+    assert len(sort) == 3  # one tile per wave (lists up to 1024 / up to 2048 keys in registers), one tile per workgroup
+    for k, s in sort.items():
+        # no spills; LDS (32 KB, four workgroups per CU) for the long-list path / the workgroup kernel's merge buffers.  The
+        # 16-keys-per-lane instance (frames whose lists stay below 1024 keys: workload R) must keep four waves per SIMD -- a
+        # frame of 3 225 tiles is then resident at once; the 32-keys-per-lane network costs a wave (141 VGPR)
+        assert s["ScratchSize"] == 0 and s["LDS"] <= 32 * 1024 + 64, (k, s)
+        assert s["Occupancy"] >= (3 if "k_tile_sortILi5" in k else 4), (k, s)
     fused = _resources("fused.hip")
     for k, v in fused.items():
         if "k_fproject" in k or "k_ftile_scan" in k:
