@@ -354,17 +354,36 @@ __device__ __forceinline__ void bitonic_sort_long(uint64_t* a, int n, uint64_t* 
 // needs a barrier or LDS.  Measured against the LDS version it replaces: see DESIGN.md.  Lists longer than 2048
 // entries (a pile of splats in one tile) are sorted by the whole workgroup block-wise, bitonic_sort_long.
 // ------------------------------------------------------------------------------------------------
+// I/O (round 4): the kernel WITHOUT the network took as long as with it -- its 47 us at R were the loads and stores: lane L
+// holding elements 16 L .. 16 L + 15 reads (and writes) 64 different cache lines per instruction.  The network does not care
+// where an input key starts, so the keys are loaded lane-interleaved (element r * 64 + L: one 512-byte run per instruction);
+// the sorted ids are transposed through the wave's own 8 KiB of LDS (rows rotated by the lane: no bank pile-up) and leave as
+// contiguous 256-byte runs.  `ids_lds`: 2048 ints private to this wave.
 template <int LK>
 __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src, int n, long long s, int t, int lane,
                                                uint64_t* __restrict__ keys_out, int32_t* __restrict__ flatten_ids,
                                                int64_t* __restrict__ isect_ids, int64_t cam_enc,
-                                               const int32_t* __restrict__ storage_of) {
+                                               const int32_t* __restrict__ storage_of, int32_t* ids_lds) {
   constexpr int KPT = 1 << LK;
   uint64_t k[KPT];
   int e0 = lane * KPT;
 #pragma unroll
-  for (int r = 0; r < KPT; ++r) k[r] = (e0 + r < n) ? src[e0 + r] : ~0ull;
+  for (int r = 0; r < KPT; ++r) k[r] = (r * 64 + lane < n) ? src[r * 64 + lane] : ~0ull;
   wave_sort_regs<LK>(k, lane);
+  if (LK <= 4 && !isect_ids && !keys_out) {  // (32 keys per lane: the ids' registers would cost the instance a wave per SIMD)
+#pragma unroll
+    for (int r = 0; r < KPT; ++r)
+      ids_lds[e0 + ((r + lane) & (KPT - 1))] = (e0 + r < n) ? list_id(storage_of, k[r]) : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < KPT; ++r) {
+      const int e = r * 64 + lane, row = e >> LK, col = e & (KPT - 1);
+      if (e < n) flatten_ids[s + e] = ids_lds[row * KPT + ((col + row) & (KPT - 1))];
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < KPT; ++r)
     if (e0 + r < n) {
@@ -403,8 +422,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
   int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (counts) {
     int first = tile_begin + blockIdx.x * 4;
-    int acc = 0;
-    for (int i = tid; i < first; i += 256) acc += min(counts[i], bin_cap);
+    int acc = prefix_count_share(counts, first, bin_cap, tid);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     int t_own = first + wv;
@@ -449,11 +467,12 @@ __global__ __launch_bounds__(256) void k_tile_sort(int32_t* __restrict__ tile_of
     // sorted keys go to the packed array; in place when that is also the source (every lane has read its keys
     // into registers before any lane writes)
     uint64_t* kout = write_sorted_keys ? keys : nullptr;
+    int32_t* const ids_lds = reinterpret_cast<int32_t*>(skeys) + wv * 2048;  // (this wave's quarter of the LDS block)
     if (n > 0 && n <= (64 << MAXLK)) {
-      if (n <= 256) wave_sort_tile<2>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
-      else if (n <= 512) wave_sort_tile<3>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
-      else if (MAXLK == 4 || n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
-      else wave_sort_tile<(MAXLK > 4 ? 5 : 4)>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of);
+      if (n <= 256) wave_sort_tile<2>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of, ids_lds);
+      else if (n <= 512) wave_sort_tile<3>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of, ids_lds);
+      else if (MAXLK == 4 || n <= 1024) wave_sort_tile<4>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of, ids_lds);
+      else wave_sort_tile<(MAXLK > 4 ? 5 : 4)>(src, n, s, t, lane, kout, flatten_ids, isect_ids, cam_enc, storage_of, ids_lds);
     }
   }
   // rare: lists too long for one wave, sorted in place by the whole workgroup, one after the other
@@ -661,8 +680,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_wg(int32_t* __restrict__ tile
   const int t = tile_begin + blockIdx.x;
   long long s, e;
   if (counts) {
-    int acc = 0;
-    for (int i = tid; i < t; i += 256) acc += min(counts[i], bin_cap);
+    int acc = prefix_count_share(counts, t, bin_cap, tid);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (lane == 0) s_scan[wv] = acc;

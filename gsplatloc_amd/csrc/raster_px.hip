@@ -361,8 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SORT == 3 ?
   long long sorted_rs = 0, sorted_re = 0;
   if constexpr (SORT != 0) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int acc = 0;
-    for (int i = tid; i < tile; i += 256) acc += min(fs.counts[i], fs.bin_cap);
+    int acc = prefix_count_share(fs.counts, tile, fs.bin_cap, tid);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (lane == 0) s_scan[wv] = acc;

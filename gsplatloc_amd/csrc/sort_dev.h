@@ -83,6 +83,26 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane)
   }
 }
 
+// Sum of min(counts[i], cap) over i < n by the 256 threads of a workgroup (this thread's share; the caller folds lanes and
+// waves): the offset of a tile's list = the sizes of the tiles before it.  Eight loads in flight per thread: written as
+// "for (i = tid; i < n; i += 256) acc += ..." the compiler waits for every load before it issues the next, and the last
+// workgroups of a 3 225-tile frame paid 13 dependent L2 round trips -- that loop, not the sorting network, was the sort
+// kernel's 47 us at R (round 4: the kernel WITHOUT the network took as long).
+__device__ __forceinline__ int prefix_count_share(const int32_t* __restrict__ counts, int n, int cap, int tid) {
+  int acc = 0;
+  for (int base = 0; base < n; base += 256 * 8) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + tid;
+      v[u] = (i < n) ? counts[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += min(v[u], cap);
+  }
+  return acc;
+}
+
 // smallest ia in [lo, hi] such that the first d merged elements take ia from A (keys are unique)
 __device__ __forceinline__ int merge_diag(const uint64_t* __restrict__ A, int lenA, const uint64_t* __restrict__ B, int lenB,
                                           int d) {
