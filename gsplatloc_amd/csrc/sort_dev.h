@@ -35,6 +35,40 @@ __device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, unsigned long l
          sort_sel(take, (unsigned)o, (unsigned)a);
 }
 
+// Lane exchanges of the network.  Round 4: the sort kernel's waves spent a quarter of their cycles waiting to ISSUE an LDS
+// instruction (SQ_WAIT_INST_LDS 1.4e7 of 5.8e7 wave-cycles; the compositing kernels: 0.7 %): 21 of the 55 stages of a
+// 1024-key sort exchange 16 keys x 2 dwords through ds_bpermute.  Every exchange inside a 16-lane row is a DPP pattern --
+// the flips of spans 2, 4, 8, 16 are quad_perm [1,0,3,2] / [3,2,1,0], row_half_mirror, row_mirror; the half-cleaners at
+// distance 1, 2, 8 are quad_perm [1,0,3,2] / [2,3,0,1] and row_ror:8 -- and costs a 4-cycle VALU move instead of an LDS
+// round trip; only distances 4, 16, 32 and the two widest flips stay on ds_bpermute (6 of the 21 stages).
+struct XShfl {
+  int mask;
+  __device__ __forceinline__ uint64_t operator()(uint64_t v) const { return shfl_xor_u64(v, mask); }
+};
+template <int CTRL>
+struct XDpp {
+  __device__ __forceinline__ uint64_t operator()(uint64_t v) const {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+    return ((uint64_t)hi << 32) | lo;
+  }
+};
+template <int KPT, typename X>
+__device__ __forceinline__ void flip_stage(uint64_t (&k)[KPT], X xchg, unsigned long long keep_min) {
+#pragma unroll
+  for (int r = 0; r < KPT / 2; ++r) {
+    uint64_t o_r = xchg(k[KPT - 1 - r]);
+    uint64_t o_p = xchg(k[r]);
+    k[r] = pick(k[r], o_r, keep_min);
+    k[KPT - 1 - r] = pick(k[KPT - 1 - r], o_p, keep_min);
+  }
+}
+template <int KPT, typename X>
+__device__ __forceinline__ void clean_stage(uint64_t (&k)[KPT], X xchg, unsigned long long km) {
+#pragma unroll
+  for (int r = 0; r < KPT; ++r) k[r] = pick(k[r], xchg(k[r]), km);
+}
+
 template <int LK>
 __device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane) {
   constexpr int KPT = 1 << LK;
@@ -60,18 +94,22 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane)
   for (int tb = 1; tb <= 6; ++tb) {
     int mask = (1 << tb) - 1;
     const unsigned long long keep_min = __ballot(((lane >> (tb - 1)) & 1) == 0);
-#pragma unroll
-    for (int r = 0; r < KPT / 2; ++r) {
-      uint64_t o_r = shfl_xor_u64(k[KPT - 1 - r], mask);
-      uint64_t o_p = shfl_xor_u64(k[r], mask);
-      k[r] = pick(k[r], o_r, keep_min);
-      k[KPT - 1 - r] = pick(k[KPT - 1 - r], o_p, keep_min);
+    switch (tb) {  // lane <-> lane ^ mask: the mirror of a span of 2^tb lanes
+      case 1: flip_stage<KPT>(k, XDpp<0xB1>(), keep_min); break;   // quad_perm [1,0,3,2]
+      case 2: flip_stage<KPT>(k, XDpp<0x1B>(), keep_min); break;   // quad_perm [3,2,1,0]
+      case 3: flip_stage<KPT>(k, XDpp<0x141>(), keep_min); break;  // row_half_mirror
+      case 4: flip_stage<KPT>(k, XDpp<0x140>(), keep_min); break;  // row_mirror
+      default: flip_stage<KPT>(k, XShfl{mask}, keep_min); break;
     }
 #pragma unroll 1
     for (int b = tb - 2; b >= 0; --b) {
       const unsigned long long km = __ballot(((lane >> b) & 1) == 0);
-#pragma unroll
-      for (int r = 0; r < KPT; ++r) k[r] = pick(k[r], shfl_xor_u64(k[r], 1 << b), km);
+      switch (b) {  // lane <-> lane ^ 2^b
+        case 0: clean_stage<KPT>(k, XDpp<0xB1>(), km); break;   // quad_perm [1,0,3,2]
+        case 1: clean_stage<KPT>(k, XDpp<0x4E>(), km); break;   // quad_perm [2,3,0,1]
+        case 3: clean_stage<KPT>(k, XDpp<0x128>(), km); break;  // row_ror:8
+        default: clean_stage<KPT>(k, XShfl{1 << b}, km); break;
+      }
     }
 #pragma unroll
     for (int lj = LK - 1; lj >= 0; --lj)
