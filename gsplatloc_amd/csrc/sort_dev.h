@@ -39,8 +39,8 @@ __device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, unsigned long l
 // instruction (SQ_WAIT_INST_LDS 1.4e7 of 5.8e7 wave-cycles; the compositing kernels: 0.7 %): 21 of the 55 stages of a
 // 1024-key sort exchange 16 keys x 2 dwords through ds_bpermute.  Every exchange inside a 16-lane row is a DPP pattern --
 // the flips of spans 2, 4, 8, 16 are quad_perm [1,0,3,2] / [3,2,1,0], row_half_mirror, row_mirror; the half-cleaners at
-// distance 1, 2, 8 are quad_perm [1,0,3,2] / [2,3,0,1] and row_ror:8 -- and costs a 4-cycle VALU move instead of an LDS
-// round trip; only distances 4, 16, 32 and the two widest flips stay on ds_bpermute (6 of the 21 stages).
+// distance 1, 2, 8 are quad_perm [1,0,3,2] / [2,3,0,1] and row_ror:8, distance 4 two bank-masked row shifts -- and costs 4-cycle
+// VALU moves instead of an LDS round trip; only distance 16 and the two widest flips stay on ds_bpermute (3 of the 21 stages).
 struct XShfl {
   int mask;
   __device__ __forceinline__ uint64_t operator()(uint64_t v) const { return shfl_xor_u64(v, mask); }
@@ -51,6 +51,15 @@ struct XDpp {
     const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
     const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
     return ((uint64_t)hi << 32) | lo;
+  }
+};
+struct XDppXor4 {  // lane <-> lane ^ 4: banks 0, 2 of a row take lane + 4 (row_shl:4), banks 1, 3 lane - 4 (row_shr:4)
+  __device__ __forceinline__ static unsigned one(unsigned v) {
+    int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xF, 0xA, false);
+  }
+  __device__ __forceinline__ uint64_t operator()(uint64_t v) const {
+    return ((uint64_t)one((unsigned)(v >> 32)) << 32) | one((unsigned)v);
   }
 };
 template <int KPT, typename X>
@@ -107,6 +116,7 @@ __device__ __forceinline__ void wave_sort_regs(uint64_t (&k)[1 << LK], int lane)
       switch (b) {  // lane <-> lane ^ 2^b
         case 0: clean_stage<KPT>(k, XDpp<0xB1>(), km); break;   // quad_perm [1,0,3,2]
         case 1: clean_stage<KPT>(k, XDpp<0x4E>(), km); break;   // quad_perm [2,3,0,1]
+        case 2: clean_stage<KPT>(k, XDppXor4(), km); break;
         case 3: clean_stage<KPT>(k, XDpp<0x128>(), km); break;  // row_ror:8
         default: clean_stage<KPT>(k, XShfl{1 << b}, km); break;
       }
