@@ -204,9 +204,11 @@ def pmc_kernels():
 
 
 def issue_bound(stage, launch_ms):
-    """The bound the compositing kernels actually run against: VALU issue.  Instructions per launch
-    from the hash-matched SQ-counter summary; priced per class with the measured issue costs (ISSUE_NS) at the static
-    class mix of the kernel's hot loop (scripts/issue_model.py), next to the all-fast and all-slow prices."""
+    """The bound the compositing kernels actually run against: VALU issue.  `frac` = the measured
+    occupancy of the vector ALUs during the launch (hash-matched SQ-counter summary).  Next to it the instruction counts
+    and what they would cost if every 2-cycle instruction found a partner (the static class mix of the kernel's hot loop,
+    scripts/issue_model.py, priced with the issue costs of profiles/r04_valu_issue.txt): the gap between the two is why
+    removing 4-cycle instructions paid half of what that model promised."""
     ks = pmc_kernels()
     if not ks:
         return None
@@ -235,8 +237,16 @@ def issue_bound(stage, launch_ms):
         tot = float(mix["fast"] + mix["slow"] + mix["trans"])
         ns = (mix["fast"] * ISSUE_NS["fast"] + mix["slow"] * ISSUE_NS["slow"] + mix["trans"] * ISSUE_NS["trans"]) / tot
         out["hot_loop_class_mix"] = {c: mix[c] / tot for c in ("fast", "slow", "trans")}
-        out["issue_peak_us"] = valu * ns / simds * 1e-3
-        out["frac"] = out["issue_peak_us"] / (launch_ms * 1e3) if launch_ms else None
+        out["issue_us_if_every_2_cycle_op_paired"] = valu * ns / simds * 1e-3
+        out["frac_if_every_2_cycle_op_paired"] = out["issue_us_if_every_2_cycle_op_paired"] / (launch_ms * 1e3) if launch_ms else None
+    # THE measurement: cycles in which a SIMD's vector ALU was occupied by an instruction (SQ_ACTIVE_INST_VALU, counted
+    # in units of 4 cycles like SQ_WAVE_CYCLES) over the SIMD-cycles of the launch (1024 SIMDs x the launch's cycles,
+    # SQ_BUSY_CYCLES per shader engine), from the same counter run: in the mixed instruction stream of a compositing
+    # trip the 2-cycle instructions do NOT pair up -- the kernels average 4.1 cycles per VALU instruction
+    if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_BUSY_CYCLES_per_se") and valu:
+        out["valu_busy_frac"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * sq["SQ_BUSY_CYCLES_per_se"])
+        out["cycles_per_valu_inst"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / valu
+        out["frac"] = out["valu_busy_frac"]
     return out
 
 
