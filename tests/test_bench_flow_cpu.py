@@ -51,6 +51,7 @@ def test_two_ranks_as_the_harness_launches_them():
     assert len(lines) == 1, res.stdout[-2000:]  # rank 0 only
     d = _check(lines[0], 2)
     assert d["cpu_baseline"] is None and "2 screen-tile strips" in d["config"]["parallelism"]
+    assert d["config"]["strip_lists_match_full_frame_rank0"] is True
     rows = d["config"]["tile_rows_rank0"]
     assert rows[0] == 0 and 0 < rows[1] < 15  # rank 0 owns the top strip of the 15 tile rows
 

@@ -73,6 +73,9 @@ def test_two_rank_bench_with_graph_replay(repo_root):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["launch"].startswith("hipGraph replay") and d["scaling"] == "strong"
     assert "2 screen-tile strips" in d["config"]["parallelism"] and d["value"] > 0
+    # the strip was cut out of the caller's arrays with caller-order indices and holds the full frame's lists of its rows
+    # (round 4: a placed calibration context had handed out storage-order indices -- half the intersections went missing)
+    assert d["config"]["strip_lists_match_full_frame_rank0"] is True
 
 
 def test_graph_tracker_two_ranks_match_one(tmp_path, repo_root):
