@@ -100,6 +100,14 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
 // one interleaved array of 64-byte rows made the random-order forward 10 % faster and projection / binning slower,
 // no net gain; a workgroup -> tile map that gives each XCD one contiguous span of tiles changed nothing.)
 #define GSL_Q(arr, g) (arr)[(g)]
+// Pixel groups of an 8x8 quadrant in the compositing backward (raster_g16.hip): 4 = the four 4x4 blocks (one DPP row
+// of 16 lanes each), 8 = the eight 4x2 half blocks (8 lanes each).  The forward's hit list carries one bit per group
+// above the entry's list index: (group bits) << GSL_HIT_SHIFT | index.
+#ifndef GSL_NG
+#define GSL_NG 4
+#endif
+#define GSL_HIT_SHIFT (32 - GSL_NG)
+#define GSL_HIT_INDEX_MASK ((1u << GSL_HIT_SHIFT) - 1u)
 // Workgroup -> work item.  Workgroups go to the eight XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has
 // its own 4 MiB L2.  With GSL_XCD_SPANS the items (tiles, in raster order) are dealt so that XCD x gets ONE contiguous
 // span of them: with the Gaussians stored in tile order (context.py:_choose_placement) the records an XCD gathers are

@@ -44,6 +44,10 @@ __device__ __forceinline__ float g16_sel(unsigned long long m, float t, float f)
 #define G16_M_B1 0x3333333333333333ull   // bit 1 of p clear
 #define G16_M_B0 0x5555555555555555ull   // bit 0 of p clear
 
+constexpr int G16_NG = GSL_NG;       // pixel groups (walk lists) per quadrant: 4 (4x4 blocks) or 8 (4x2 half blocks)
+constexpr int G16_GL = 64 / G16_NG;  // lanes per group
+static_assert(G16_NG == 4 || G16_NG == 8, "pixel groups are DPP rows or half rows");
+
 // Reduce-scatter of 8 values over a 16-lane DPP row: returns, in lane p, the row total of value (p >> 1)
 // (even and odd lane of a pair hold the same total).  4 + 2 + 1 exchange steps with halving payload + 1 plain add.
 //
@@ -104,6 +108,46 @@ __device__ __forceinline__ float row_scatter16(const float (&v)[16]) {
   return keep + dpp_get<0xB1>(send);
 }
 
+// Half-row forms (GSL_NG = 8: a group is the 8 lanes of half a DPP row, two quads).  One bank-masked mirror step inside
+// the half row leaves quad 0 with the pair sums of values 0-3 and quad 1 with those of values 4-7 (value 7: padding); two
+// butterfly steps inside the quads then give EVERY lane of quad q the group totals of values 4q .. 4q+3, which its first
+// lane stores as one float4.  7 + 8 = 15 DPP adds for a group of 8 lanes against 15 instructions for 16 lanes above: per
+// trip the same, but the half blocks skip what the 4x4 blocks only half use.
+__device__ __forceinline__ float4 half_scatter8(const float (&v)[8]) {
+  float n0, n1, n2, n3;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"  // p <-> 7 - p inside each half row
+      "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   // banks 1, 3: the second quad of a group
+      "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 1\n\t"  // (the compiler's DPP reads of n0 .. n3 follow; it does not see VALU writes inside an asm block)
+      : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]));
+  n0 += dpp_get<0x4E>(n0); n1 += dpp_get<0x4E>(n1); n2 += dpp_get<0x4E>(n2); n3 += dpp_get<0x4E>(n3);
+  n0 += dpp_get<0xB1>(n0); n1 += dpp_get<0xB1>(n1); n2 += dpp_get<0xB1>(n2); n3 += dpp_get<0xB1>(n3);
+  return make_float4(n0, n1, n2, n3);
+}
+
+// 16 values over a half row: every lane of quad q ends with the group totals of values 8q .. 8q+7 (lo: the first four).
+__device__ __forceinline__ void half_scatter16(const float (&v)[16], float4& lo, float4& hi) {
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float keep = g16_sel(G16_M_B2, v[i], v[i + 8]), send = g16_sel(G16_M_B2, v[i + 8], v[i]);
+    a[i] = keep + dpp_get<0x141>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] += dpp_get<0x4E>(a[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] += dpp_get<0xB1>(a[i]);
+  lo = make_float4(a[0], a[1], a[2], a[3]);
+  hi = make_float4(a[4], a[5], a[6], a[7]);
+}
+
 #ifdef GSL_G16_STATS  // dev build only: trip statistics of the walk (scripts/g16_stats.py)
 __device__ unsigned long long g16_stats[8];
 #define G16_STAT(i, n) do { unsigned long long n__ = (unsigned long long)(n); if (lane == 0) atomicAdd(&g16_stats[i], n__); } while (0)
@@ -124,14 +168,16 @@ struct QStage {
   static constexpr int NV = 6 + CG;
   static constexpr int NS = (NV <= 8) ? 8 : 16;
   static constexpr int A = 6 + D;
-  static constexpr int LCAP = (NS == 8) ? GSL_Q_LCAP : GSL_Q_LCAP / 2;  // trips per row per round: 4 rows x LCAP x NS floats
+  // trips per group per round: NG groups x LCAP x NS floats = 4 KiB
+  static constexpr int LCAP = ((NS == 8) ? GSL_Q_LCAP : GSL_Q_LCAP / 2) * 4 / G16_NG;
   float4 s0[GSL_QBS];
   float4 s1[GSL_QBS];  // .w = the entry's absolute list index (bits), not r_cull: the walk tests it against last_ids
   float4 s2[(D >= 3 && CG == D) ? GSL_QBS : 1];
   int32_t id[GSL_QBS];
-  uint32_t posn[GSL_QBS];                  // per slot: position in each row list (7 bits each) | row nibble << 28
-  alignas(16) float pair[4 * LCAP * NS];   // [row][trip of the round][slot]; reused for 64 packed gradient rows
-  uint8_t rlist[4][GSL_QBS + 4];           // per row: slots in walk order, padded with the sentinel slot
+  // per slot, word w: position in the lists of groups 4w .. 4w+3 (7 bits each) | those groups' hit bits << 28
+  uint32_t posn[G16_NG / 4][GSL_QBS];
+  alignas(16) float pair[G16_NG * LCAP * NS];  // [group][trip of the round][value]; reused for 64 packed gradient rows
+  uint8_t rlist[G16_NG][GSL_QBS + 4];          // per group: slots in walk order, padded with the sentinel slot
   uint8_t nzlist[64];
 };
 
@@ -147,30 +193,34 @@ __device__ __forceinline__ void qraster_bwd_body(
   constexpr int NS = QStage<D, CG>::NS;
   constexpr int A = QStage<D, CG>::A;
   constexpr int LCAP = QStage<D, CG>::LCAP;
-  static_assert(4 * LCAP * NS >= 64 * 16, "64 packed gradient rows reuse the pair slots");
+  constexpr int NG = G16_NG, GL = G16_GL;
+  static_assert(NG * LCAP * NS >= 64 * 16, "64 packed gradient rows reuse the pair slots");
   static_assert(GSL_QB <= 127 && GSL_QB >= 64, "slots are bytes; a chunk appends up to 64 entries");
-  const int grp = lane >> 4, p = lane & 15;
+  const int grp = lane / GL, p = lane & (GL - 1);
   const float tcx = tx0 + 8.f, tcy = ty0 + 8.f;
   const float lx = px - tcx, ly = py - tcy;
   const float lxx = lx * lx, lxy = lx * ly, lyy = ly * ly;
   float T = T_init;
   float Bp = Bp_init;
-  const int myslot = (NS == 8) ? (p >> 1) : p;
-  const bool writer = (NS == 8) ? ((p & 1) == 0) : true;
+  // which lane stores which totals of a trip.  Rows (NG = 4): lane p holds the total of value p >> 1 (NS = 8) or p (16)
+  // and stores one float.  Half rows (NG = 8): every lane of quad q holds the totals of the q-th half of the values and
+  // the quad's first lane stores them as float4s.
+  const int myslot = (NG == 8) ? (p >> 2) * (NS / 2) : ((NS == 8) ? (p >> 1) : p);
+  const bool writer = (NG == 8) ? ((p & 3) == 0) : ((NS == 8) ? ((p & 1) == 0) : true);
   float* const mypair = &sb.pair[grp * LCAP * NS + myslot];
   uint8_t* const mylist = sb.rlist[grp];
   const unsigned long long lt = (1ull << lane) - 1ull;
-  // block rectangles of this quadrant's rows (geometric fallback when the forward left no hit masks)
+  // group rectangles of this quadrant (geometric fallback when the forward left no hit masks)
   const float qx0 = tx0 + 8.f * (float)(quad & 1), qy0 = ty0 + 8.f * (float)(quad >> 1);
-  int row_final[4];  // per row: last list index any of its pixels composited (fallback test only)
+  int grp_final[NG];  // per group: last list index any of its pixels composited (fallback test only)
   {
     int rf = bin_final;
     rf = max(rf, __shfl_xor(rf, 1, 64));
     rf = max(rf, __shfl_xor(rf, 2, 64));
     rf = max(rf, __shfl_xor(rf, 4, 64));
-    rf = max(rf, __shfl_xor(rf, 8, 64));
+    if (GL == 16) rf = max(rf, __shfl_xor(rf, 8, 64));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) row_final[g] = __builtin_amdgcn_readlane(rf, 16 * g);
+    for (int g = 0; g < NG; ++g) grp_final[g] = __builtin_amdgcn_readlane(rf, GL * g);
   }
   if (lane == 0) {  // the sentinel record: opacity 0 fails alpha >= 1/255 on every pixel
     sb.s0[GSL_QB] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -178,14 +228,16 @@ __device__ __forceinline__ void qraster_bwd_body(
     if (RGB && CG == D) sb.s2[GSL_QB] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // What is scanned, back to front, 64 per step: this quadrant's hit list from the forward (qhits: n_qhits entries of
-  // nibble << 28 | list index, every one of them relevant), or -- without it -- the tile's list itself, with the
-  // block tests done here.
+  // group bits << GSL_HIT_SHIFT | list index, every one of them relevant), or -- without it -- the tile's list itself,
+  // with the group tests done here.
   long long pos = qhits ? (long long)n_qhits : re;
   const long long pos_end = qhits ? 0 : rs;
   while (pos > pos_end) {
     // ---- stage: scan chunks of 64 until the batch is (nearly) full
     int staged = 0;
-    int cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    int cnt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) cnt[g] = 0;
     __syncthreads();  // (one wave: orders the previous batch's LDS reads before these writes)
     while (pos > pos_end && staged <= GSL_QB - 64) {
       long long idx = pos - 1 - lane;
@@ -196,8 +248,8 @@ __device__ __forceinline__ void qraster_bwd_body(
       if (in) {
         if (qhits) {
           unsigned e = qhits[idx];
-          nib = e >> 28;
-          idx = (long long)(e & 0x0FFFFFFFu);
+          nib = e >> GSL_HIT_SHIFT;
+          idx = (long long)(e & GSL_HIT_INDEX_MASK);
           gid = flatten_ids[idx];
           load_record(Q0, Q1, Q2, Qh, gid, RGB && CG == D, r0, r1, r2);
         } else {
@@ -206,10 +258,13 @@ __device__ __forceinline__ void qraster_bwd_body(
           if (r1.w >= 0.f) {
             float rr = r1.w * r1.w;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              float ex = fmaxf(fabsf(r0.x - (qx0 + 4.f * (float)(g & 1) + 2.f)) - 1.5f, 0.f);
-              float ey = fmaxf(fabsf(r0.y - (qy0 + 4.f * (float)(g >> 1) + 2.f)) - 1.5f, 0.f);
-              bool h = (ex * ex + ey * ey <= rr) && ((int)idx <= row_final[g]);
+            for (int g = 0; g < NG; ++g) {
+              // group g: block b = g (NG = 4) or g >> 1 with its upper / lower two pixel rows (NG = 8)
+              const int b = (NG == 8) ? (g >> 1) : g;
+              const float cy = (NG == 8) ? 2.f * (float)(g & 1) + 1.f : 2.f, hy = (NG == 8) ? 0.5f : 1.5f;
+              float ex = fmaxf(fabsf(r0.x - (qx0 + 4.f * (float)(b & 1) + 2.f)) - 1.5f, 0.f);
+              float ey = fmaxf(fabsf(r0.y - (qy0 + 4.f * (float)(b >> 1) + cy)) - hy, 0.f);
+              bool h = (ex * ex + ey * ey <= rr) && ((int)idx <= grp_final[g]);
               nib |= (h ? 1u : 0u) << g;
             }
           }
@@ -217,12 +272,19 @@ __device__ __forceinline__ void qraster_bwd_body(
       }
       unsigned long long R = __ballot(nib != 0);
       int slot = staged + __popcll(R & lt);
-      unsigned pack = nib << 28;
-      unsigned long long B0 = __ballot(nib & 1u), B1 = __ballot(nib & 2u), B2 = __ballot(nib & 4u), B3 = __ballot(nib & 8u);
-      if (nib & 1u) { int q = cnt0 + __popcll(B0 & lt); sb.rlist[0][q] = (uint8_t)slot; pack |= (unsigned)q; }
-      if (nib & 2u) { int q = cnt1 + __popcll(B1 & lt); sb.rlist[1][q] = (uint8_t)slot; pack |= (unsigned)q << 7; }
-      if (nib & 4u) { int q = cnt2 + __popcll(B2 & lt); sb.rlist[2][q] = (uint8_t)slot; pack |= (unsigned)q << 14; }
-      if (nib & 8u) { int q = cnt3 + __popcll(B3 & lt); sb.rlist[3][q] = (uint8_t)slot; pack |= (unsigned)q << 21; }
+      unsigned pack[NG / 4];
+#pragma unroll
+      for (int w = 0; w < NG / 4; ++w) pack[w] = ((nib >> (4 * w)) & 15u) << 28;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        unsigned long long Bg = __ballot(nib & (1u << g));
+        if (nib & (1u << g)) {
+          int q = cnt[g] + __popcll(Bg & lt);
+          sb.rlist[g][q] = (uint8_t)slot;
+          pack[g >> 2] |= (unsigned)q << (7 * (g & 3));
+        }
+        cnt[g] += __popcll(Bg);
+      }
       if (nib) {
         sb.id[slot] = gid;
         sb.s0[slot] = r0;
@@ -232,18 +294,24 @@ __device__ __forceinline__ void qraster_bwd_body(
         sb.s1[slot] = make_float4(r1.x * (0.5f * GSL_LOG2E), r1.y * GSL_LOG2E, r1.z * (0.5f * GSL_LOG2E),
                                   __int_as_float((int)idx));
         if (RGB && CG == D) sb.s2[slot] = r2;
-        sb.posn[slot] = pack;
+#pragma unroll
+        for (int w = 0; w < NG / 4; ++w) sb.posn[w][slot] = pack[w];
       }
-      cnt0 += __popcll(B0); cnt1 += __popcll(B1); cnt2 += __popcll(B2); cnt3 += __popcll(B3);
       staged += __popcll(R);
       pos -= 64;
     }
     if (staged == 0) continue;
-    const int kmax = max(max(cnt0, cnt1), max(cnt2, cnt3));
+    int kmax = 0, cnt_tot = 0, cnt_my = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      kmax = max(kmax, cnt[g]);
+      cnt_tot += cnt[g];
+      cnt_my = (grp == g) ? cnt[g] : cnt_my;
+    }
     G16_STAT(6, kmax);
-    G16_STAT(7, cnt0 + cnt1 + cnt2 + cnt3);
-    const int cnt = grp == 0 ? cnt0 : (grp == 1 ? cnt1 : (grp == 2 ? cnt2 : cnt3));
-    for (int k = cnt + p; k < kmax + 2; k += 16) mylist[k] = (uint8_t)GSL_QB;  // sentinel padding (+2: read-ahead)
+    G16_STAT(7, cnt_tot);
+    (void)cnt_tot;
+    for (int k = cnt_my + p; k < kmax + 2; k += GL) mylist[k] = (uint8_t)GSL_QB;  // sentinel padding (+2: read-ahead)
     __syncthreads();
     float mo[2][NV];
 #pragma unroll
@@ -255,13 +323,20 @@ __device__ __forceinline__ void qraster_bwd_body(
       int t_cur = mylist[k0];
       int t_nxt = mylist[k0 + 1];
       float4 q0 = sb.s0[t_cur], q1 = sb.s1[t_cur];
-      float r_prev = 0.f;
+      float4 r_prev = make_float4(0.f, 0.f, 0.f, 0.f), r_prev2 = r_prev;  // (rows: .x only)
       bool st_prev = false;
       float* dst_prev = mypair;
       for (int k = k0; k < k1; ++k) {
         const int t = t_cur;
         const float4 c0 = q0, c1 = q1;
-        if (st_prev) *dst_prev = r_prev;  // (stores before the next loads: the LDS queue is in order)
+        if (st_prev) {  // (stores before the next loads: the LDS queue is in order)
+          if (NG == 8) {
+            *reinterpret_cast<float4*>(dst_prev) = r_prev;
+            if (NS == 16) *reinterpret_cast<float4*>(dst_prev + 4) = r_prev2;
+          } else {
+            *dst_prev = r_prev.x;
+          }
+        }
         t_cur = t_nxt;
         t_nxt = mylist[k + 2];
         q0 = sb.s0[t_cur];
@@ -274,11 +349,10 @@ __device__ __forceinline__ void qraster_bwd_body(
         unsigned long long validm = __ballot(__float_as_int(c1.w) <= bin_final) & __ballot(sigma >= 0.f) &
                                     __ballot(alpha >= GSL_ALPHA_MIN);
         G16_STAT(0, 1);
-        G16_STAT(2, __popcll(__ballot(k < cnt)) >> 4);
-        float r = 0.f;
+        G16_STAT(2, __popcll(__ballot(k < cnt_my)) / GL);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r;
         if (validm) {
           G16_STAT(1, 1);
-          G16_STAT(3, ((validm & 0xFFFFull) != 0) + ((validm & 0xFFFF0000ull) != 0) + ((validm & 0xFFFF00000000ull) != 0) + ((validm >> 48) != 0));
           G16_STAT(5, __popcll(validm));
           unsigned long long capm = __ballot(opv <= GSL_ALPHA_MAX);
           float am = g16_sel(validm, alpha, 0.f);
@@ -309,35 +383,52 @@ __device__ __forceinline__ void qraster_bwd_body(
           }
 #pragma unroll
           for (int q = NV; q < NS; ++q) val[q] = 0.f;
-          static_assert(NS != 8 || NV == 7, "row_scatter8 treats value 7 as padding");
-          if (NS == 8) r = row_scatter8(reinterpret_cast<const float(&)[8]>(val));
-          else r = row_scatter16(reinterpret_cast<const float(&)[16]>(val));
+          static_assert(NS != 8 || NV == 7, "the 8-value scatters treat value 7 as padding");
+          if (NG == 8) {
+            if (NS == 8) r = half_scatter8(reinterpret_cast<const float(&)[8]>(val));
+            else half_scatter16(reinterpret_cast<const float(&)[16]>(val), r, r2);
+          } else {
+            if (NS == 8) r.x = row_scatter8(reinterpret_cast<const float(&)[8]>(val));
+            else r.x = row_scatter16(reinterpret_cast<const float(&)[16]>(val));
+          }
         }
         r_prev = r;
+        r_prev2 = r2;
         st_prev = writer;
         dst_prev = &mypair[(k - k0) * NS];
       }
-      if (st_prev) *dst_prev = r_prev;
+      if (st_prev) {
+        if (NG == 8) {
+          *reinterpret_cast<float4*>(dst_prev) = r_prev;
+          if (NS == 16) *reinterpret_cast<float4*>(dst_prev + 4) = r_prev2;
+        } else {
+          *dst_prev = r_prev.x;
+        }
+      }
       __syncthreads();
-      // gather: lane L adds up the pairs of slots L and L + 64 that lie in this round, in row order
+      // gather: lane L adds up the pairs of slots L and L + 64 that lie in this round, in group order
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         int slot = lane + 64 * u;
         if (slot < staged) {
-          unsigned pk = sb.posn[slot];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            int q = (int)((pk >> (7 * g)) & 127u) - k0;
-            if (((pk >> (28 + g)) & 1u) && q >= 0 && q < LCAP) {
-              const float4* src = reinterpret_cast<const float4*>(&sb.pair[(g * LCAP + q) * NS]);
-              float4 a = src[0], c = src[1];
-              mo[u][0] += a.x; mo[u][1] += a.y; mo[u][2] += a.z; mo[u][3] += a.w;
-              mo[u][4] += c.x; mo[u][5] += c.y; mo[u][6] += c.z;
-              if (NV > 7) mo[u][7 < NV ? 7 : 0] += c.w;
-              if (NS == 16) {
-                float4 e = src[2];
-                if (NV > 8) mo[u][8 < NV ? 8 : 0] += e.x;
-                if (NV > 9) mo[u][9 < NV ? 9 : 0] += e.y;
+          for (int w = 0; w < NG / 4; ++w) {
+            unsigned pk = sb.posn[w][slot];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+              const int g = 4 * w + g4;
+              int q = (int)((pk >> (7 * g4)) & 127u) - k0;
+              if (((pk >> (28 + g4)) & 1u) && q >= 0 && q < LCAP) {
+                const float4* src = reinterpret_cast<const float4*>(&sb.pair[(g * LCAP + q) * NS]);
+                float4 a = src[0], c = src[1];
+                mo[u][0] += a.x; mo[u][1] += a.y; mo[u][2] += a.z; mo[u][3] += a.w;
+                mo[u][4] += c.x; mo[u][5] += c.y; mo[u][6] += c.z;
+                if (NV > 7) mo[u][7 < NV ? 7 : 0] += c.w;
+                if (NS == 16) {
+                  float4 e = src[2];
+                  if (NV > 8) mo[u][8 < NV ? 8 : 0] += e.x;
+                  if (NV > 9) mo[u][9 < NV ? 9 : 0] += e.y;
+                }
               }
             }
           }

@@ -106,12 +106,15 @@ __device__ __forceinline__ void pixel_masks(int lox, int hix, int loy, int hiy, 
   mhi = chi & rhi;
 }
 
-// OR over the 16 lanes of a DPP row (every lane of the row gets the result).
-__device__ __forceinline__ unsigned row_or(unsigned v) {
+// OR over the lanes of a pixel group of the backward: the 16 lanes of a DPP row (GSL_NG = 4) or the 8 of a half row
+// (GSL_NG = 8); every lane of the group gets the result.
+__device__ __forceinline__ unsigned group_or(unsigned v) {
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+#if GSL_NG == 4
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+#endif
   return v;
 }
 
@@ -152,7 +155,7 @@ __device__ __forceinline__ void praster_walk(
   int nb = (int)((re - rs + 255) / 256);
   if (MODE == 1) isect_hits = nullptr;
   // isect_hits (may be NULL): this quadrant's HIT LIST -- the entries of [rs, re) that at least one of its pixels
-  // composited, in list order, each as (nibble of its four 4x4 blocks that did) << 28 | absolute list index, appended
+  // composited, in list order, each as (bits of its GSL_NG pixel groups that did) << GSL_HIT_SHIFT | absolute list index, appended
   // chunk by chunk at  isect_hits[4 rs + quadrant (re - rs) + n_hits ...]: the compositing backward walks exactly those
   // (block, entry) pairs and never scans an entry its quadrant did not touch
   uint32_t* const qout = isect_hits ? isect_hits + 4 * rs + (long long)wv * (re - rs) : nullptr;
@@ -286,19 +289,19 @@ __device__ __forceinline__ void praster_walk(
         cur_idx = any ? (int)bstart + tl : cur_idx;
       }
       if (isect_hits) {
-        // per DPP row (= 4x4 block): OR of the pixels' composited-candidate masks; lane e then owns candidate c + e
-        // and collects its bit from the four rows
-        unsigned rlo = row_or(cm[0]), rhi = row_or(cm[1]);
+        // per pixel group (GSL_NG = 4: DPP row = 4x4 block; 8: half row = 4x2 half block): OR of the pixels'
+        // composited-candidate masks; lane e then owns candidate c + e and collects its bit from the groups
+        unsigned rlo = group_or(cm[0]), rhi = group_or(cm[1]);
         unsigned nib = 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          unsigned glo = (unsigned)__builtin_amdgcn_readlane((int)rlo, 16 * g);
-          unsigned ghi = (unsigned)__builtin_amdgcn_readlane((int)rhi, 16 * g);
+        for (int g = 0; g < GSL_NG; ++g) {
+          unsigned glo = (unsigned)__builtin_amdgcn_readlane((int)rlo, (64 / GSL_NG) * g);
+          unsigned ghi = (unsigned)__builtin_amdgcn_readlane((int)rhi, (64 / GSL_NG) * g);
           unsigned long long gm = ((unsigned long long)ghi << 32) | glo;
           nib |= (unsigned)((gm >> lane) & 1ull) << g;
         }
         unsigned long long Rm = __ballot(nib != 0);  // (a set bit implies e < n)
-        if (nib) qout[n_hits + __popcll(Rm & ((1ull << lane) - 1ull))] = (nib << 28) | (unsigned)((int)bstart + (sb.qlist[wv][e] >> 4));
+        if (nib) qout[n_hits + __popcll(Rm & ((1ull << lane) - 1ull))] = (nib << GSL_HIT_SHIFT) | (unsigned)((int)bstart + (sb.qlist[wv][e] >> 4));
         n_hits += __popcll(Rm);
       }
     }
@@ -896,7 +899,7 @@ extern "C" int gsl_fused_raster_fwd(const float* Q0, const float* Q1, const floa
   if (capacity > 0 && !Qh && (!Q0 || !Q1 || (channels >= 3 && !Q2))) return GSL_ERR_BAD_ARG;
   if (ed && channels == 3) return GSL_ERR_BAD_ARG;
   if (isect_hits && !isect_hit_counts) return GSL_ERR_BAD_ARG;
-  if (isect_hits && capacity >= ((int64_t)1 << 28)) return GSL_ERR_BAD_ARG;  // a hit entry keeps the list index in 28 bits
+  if (isect_hits && capacity >= ((int64_t)1 << GSL_HIT_SHIFT)) return GSL_ERR_BAD_ARG;  // a hit entry keeps the list index below its group bits
   const bool sort = sort_bins != nullptr;
   if (sort && (!binned_ws || !n_isects || bin_cap <= 0 || bin_cap > 2048 || long_min != 0 || ty0 != 0 || ty1 != tile_h ||
                !flatten_ids))
