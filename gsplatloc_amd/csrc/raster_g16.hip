@@ -230,8 +230,10 @@ __device__ __forceinline__ void qraster_bwd_body(
   // What is scanned, back to front, 64 per step: this quadrant's hit list from the forward (qhits: n_qhits entries of
   // group bits << GSL_HIT_SHIFT | list index, every one of them relevant), or -- without it -- the tile's list itself,
   // with the group tests done here.
-  long long pos = qhits ? (long long)n_qhits : re;
-  const long long pos_end = qhits ? 0 : rs;
+  // (list positions fit an int: tile_offsets is int32.  readfirstlane: the scan, batch and trip loops below are
+  // wave-uniform, and the compiler has to know it to keep their control on the scalar unit)
+  int pos = __builtin_amdgcn_readfirstlane(qhits ? n_qhits : (int)re);
+  const int pos_end = __builtin_amdgcn_readfirstlane(qhits ? 0 : (int)rs);
   while (pos > pos_end) {
     // ---- stage: scan chunks of 64 until the batch is (nearly) full
     int staged = 0;
@@ -240,8 +242,8 @@ __device__ __forceinline__ void qraster_bwd_body(
     for (int g = 0; g < NG; ++g) cnt[g] = 0;
     __syncthreads();  // (one wave: orders the previous batch's LDS reads before these writes)
     while (pos > pos_end && staged <= GSL_QB - 64) {
-      long long idx = pos - 1 - lane;
-      bool in = idx >= pos_end;
+      long long idx = (long long)(pos - 1 - lane);
+      bool in = idx >= (long long)pos_end;
       unsigned nib = 0;
       int gid = 0;
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
@@ -311,100 +313,110 @@ __device__ __forceinline__ void qraster_bwd_body(
     G16_STAT(6, kmax);
     G16_STAT(7, cnt_tot);
     (void)cnt_tot;
-    for (int k = cnt_my + p; k < kmax + 2; k += GL) mylist[k] = (uint8_t)GSL_QB;  // sentinel padding (+2: read-ahead)
+    for (int k = cnt_my + p; k < kmax + 3; k += GL) mylist[k] = (uint8_t)GSL_QB;  // sentinel padding (+3: read-ahead)
     __syncthreads();
     float mo[2][NV];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int q = 0; q < NV; ++q) mo[u][q] = 0.f;
+    // One trip: the gradient sums of list entry (slot t, records c0 / c1) over this lane's pixel group, r (and r2)
+    // = what this lane stores of them.
+    auto trip = [&](int t, const float4& c0, const float4& c1, float4& r, float4& r2) {
+      float dx = c0.x - px, dy = c0.y - py;
+      float sigma = fmaf(c1.y * dx, dy, fmaf(c1.x * dx, dx, c1.z * dy * dy));  // log2(e) sigma, the forward's expression
+      float vis = __builtin_amdgcn_exp2f(-sigma);
+      float opv = c0.w * vis;
+      float alpha = fminf(GSL_ALPHA_MAX, opv);
+      unsigned long long validm = __ballot(__float_as_int(c1.w) <= bin_final) & __ballot(sigma >= 0.f) &
+                                  __ballot(alpha >= GSL_ALPHA_MIN);
+      G16_STAT(0, 1);
+      r = make_float4(0.f, 0.f, 0.f, 0.f);
+      r2 = r;
+      if (validm) {
+        G16_STAT(1, 1);
+#ifdef GSL_G16_STATS
+        {
+          int groups_hit = 0;
+          for (int g = 0; g < NG; ++g) groups_hit += ((validm >> (GL * g)) & ((1ull << GL) - 1ull)) != 0;
+          G16_STAT(3, groups_hit);
+        }
+#endif
+        G16_STAT(5, __popcll(validm));
+        unsigned long long capm = __ballot(opv <= GSL_ALPHA_MAX);
+        float am = g16_sel(validm, alpha, 0.f);
+        float ra = __builtin_amdgcn_rcpf(1.f - am);
+        T *= ra;
+        float fac = am * T;
+        float cdot;
+        if (CG == D) {
+          cdot = 0.f;
+          if (RGB) {
+            float4 q2 = sb.s2[t];
+            cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
+          }
+          if (DEPTH) cdot += c0.z * vc[D - 1];
+        } else {
+          cdot = c0.z * vc[D - 1];
+        }
+        float v_alpha = T * cdot - ra * Bp;
+        Bp += fac * cdot;
+        float w = g16_sel(validm & capm, vis, 0.f) * v_alpha;
+        float val[NS];
+        val[0] = w; val[1] = w * lx; val[2] = w * ly; val[3] = w * lxx; val[4] = w * lxy; val[5] = w * lyy;
+        if (CG == D) {
+#pragma unroll
+          for (int ch = 0; ch < D; ++ch) val[6 + ch] = fac * vc[ch];
+        } else {
+          val[6] = fac * vc[D - 1];
+        }
+#pragma unroll
+        for (int q = NV; q < NS; ++q) val[q] = 0.f;
+        static_assert(NS != 8 || NV == 7, "the 8-value scatters treat value 7 as padding");
+        if (NG == 8) {
+          if (NS == 8) r = half_scatter8(reinterpret_cast<const float(&)[8]>(val));
+          else half_scatter16(reinterpret_cast<const float(&)[16]>(val), r, r2);
+        } else {
+          if (NS == 8) r.x = row_scatter8(reinterpret_cast<const float(&)[8]>(val));
+          else r.x = row_scatter16(reinterpret_cast<const float(&)[16]>(val));
+        }
+      }
+    };
+    auto put = [&](float* dst, const float4& r, const float4& r2) {
+      if (NG == 8) {
+        *reinterpret_cast<float4*>(dst) = r;
+        if (NS == 16) *reinterpret_cast<float4*>(dst + 4) = r2;
+      } else {
+        *dst = r.x;
+      }
+    };
     for (int k0 = 0; k0 < kmax; k0 += LCAP) {
       const int k1 = min(k0 + LCAP, kmax);
-      int t_cur = mylist[k0];
-      int t_nxt = mylist[k0 + 1];
-      float4 q0 = sb.s0[t_cur], q1 = sb.s1[t_cur];
-      float4 r_prev = make_float4(0.f, 0.f, 0.f, 0.f), r_prev2 = r_prev;  // (rows: .x only)
-      bool st_prev = false;
-      float* dst_prev = mypair;
-      for (int k = k0; k < k1; ++k) {
-        const int t = t_cur;
-        const float4 c0 = q0, c1 = q1;
-        if (st_prev) {  // (stores before the next loads: the LDS queue is in order)
-          if (NG == 8) {
-            *reinterpret_cast<float4*>(dst_prev) = r_prev;
-            if (NS == 16) *reinterpret_cast<float4*>(dst_prev + 4) = r_prev2;
-          } else {
-            *dst_prev = r_prev.x;
-          }
-        }
-        t_cur = t_nxt;
-        t_nxt = mylist[k + 2];
-        q0 = sb.s0[t_cur];
-        q1 = sb.s1[t_cur];
-        float dx = c0.x - px, dy = c0.y - py;
-        float sigma = fmaf(c1.y * dx, dy, fmaf(c1.x * dx, dx, c1.z * dy * dy));  // log2(e) sigma, the forward's expression
-        float vis = __builtin_amdgcn_exp2f(-sigma);
-        float opv = c0.w * vis;
-        float alpha = fminf(GSL_ALPHA_MAX, opv);
-        unsigned long long validm = __ballot(__float_as_int(c1.w) <= bin_final) & __ballot(sigma >= 0.f) &
-                                    __ballot(alpha >= GSL_ALPHA_MIN);
-        G16_STAT(0, 1);
-        G16_STAT(2, __popcll(__ballot(k < cnt_my)) / GL);
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r;
-        if (validm) {
-          G16_STAT(1, 1);
-          G16_STAT(5, __popcll(validm));
-          unsigned long long capm = __ballot(opv <= GSL_ALPHA_MAX);
-          float am = g16_sel(validm, alpha, 0.f);
-          float ra = __builtin_amdgcn_rcpf(1.f - am);
-          T *= ra;
-          float fac = am * T;
-          float cdot;
-          if (CG == D) {
-            cdot = 0.f;
-            if (RGB) {
-              float4 q2 = sb.s2[t];
-              cdot = q2.x * vc[0] + q2.y * vc[1] + q2.z * vc[2];
-            }
-            if (DEPTH) cdot += c0.z * vc[D - 1];
-          } else {
-            cdot = c0.z * vc[D - 1];
-          }
-          float v_alpha = T * cdot - ra * Bp;
-          Bp += fac * cdot;
-          float w = g16_sel(validm & capm, vis, 0.f) * v_alpha;
-          float val[NS];
-          val[0] = w; val[1] = w * lx; val[2] = w * ly; val[3] = w * lxx; val[4] = w * lxy; val[5] = w * lyy;
-          if (CG == D) {
-#pragma unroll
-            for (int ch = 0; ch < D; ++ch) val[6 + ch] = fac * vc[ch];
-          } else {
-            val[6] = fac * vc[D - 1];
-          }
-#pragma unroll
-          for (int q = NV; q < NS; ++q) val[q] = 0.f;
-          static_assert(NS != 8 || NV == 7, "the 8-value scatters treat value 7 as padding");
-          if (NG == 8) {
-            if (NS == 8) r = half_scatter8(reinterpret_cast<const float(&)[8]>(val));
-            else half_scatter16(reinterpret_cast<const float(&)[16]>(val), r, r2);
-          } else {
-            if (NS == 8) r.x = row_scatter8(reinterpret_cast<const float(&)[8]>(val));
-            else r.x = row_scatter16(reinterpret_cast<const float(&)[16]>(val));
-          }
-        }
-        r_prev = r;
-        r_prev2 = r2;
-        st_prev = writer;
-        dst_prev = &mypair[(k - k0) * NS];
+      // Two trips per turn of the loop, records in two register sets that swap roles (round 4: a one-trip body rotated
+      // its look-ahead through seven v_mov per trip -- 12 % of its VALU slots).  The list index runs two entries and the
+      // records one entry ahead of the trip; a trip's result is stored at the start of the next one (the LDS queue is in
+      // order: stores before the next loads).  An odd count makes the second trip of the last turn an extra one: it
+      // meets sentinel slots (lists are padded to kmax + 3), finds no valid pixel and stores zeros in a pair slot of its
+      // own (the trip count of a round is even whenever the round is full) that nobody gathers.
+      int t0 = mylist[k0], t1 = mylist[k0 + 1];
+      float4 qa0 = sb.s0[t0], qa1 = sb.s1[t0];
+      float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), ra2 = ra, rb = ra, rb2 = ra;
+      float* dst = mypair;
+      for (int k = k0; k < k1; k += 2) {
+        if (k > k0 && writer) put(dst - NS, rb, rb2);
+        const int t2 = mylist[k + 2];
+        const float4 qb0 = sb.s0[t1], qb1 = sb.s1[t1];
+        trip(t0, qa0, qa1, ra, ra2);
+        if (writer) put(dst, ra, ra2);
+        const int t3 = mylist[k + 3];
+        qa0 = sb.s0[t2];
+        qa1 = sb.s1[t2];
+        trip(t1, qb0, qb1, rb, rb2);
+        t0 = t2;
+        t1 = t3;
+        dst += 2 * NS;
       }
-      if (st_prev) {
-        if (NG == 8) {
-          *reinterpret_cast<float4*>(dst_prev) = r_prev;
-          if (NS == 16) *reinterpret_cast<float4*>(dst_prev + 4) = r_prev2;
-        } else {
-          *dst_prev = r_prev.x;
-        }
-      }
+      if (writer) put(dst - NS, rb, rb2);
       __syncthreads();
       // gather: lane L adds up the pairs of slots L and L + 64 that lie in this round, in group order
 #pragma unroll

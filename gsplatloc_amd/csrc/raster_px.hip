@@ -228,7 +228,7 @@ __device__ __forceinline__ void praster_walk(
         // list slot in front of the chunk's, some valid slot of the batch whose alpha is multiplied away) instead of
         // being selected into range; the last composited index is taken from the composited mask once per chunk, not
         // selected per trip.  72 -> 62 VALU per trip, ten of the twelve removed ones of the 4-cycle kind.
-        while (__ballot(m != 0)) {
+        if (__ballot(m != 0)) do {
           const bool act = m != 0;
           const unsigned b0 = m & (0u - m);
           m ^= b0;
@@ -280,7 +280,7 @@ __device__ __forceinline__ void praster_walk(
           const bool stop = stop0 || stop1;
           done = done || stop;
           m = stop ? 0u : m;
-        }
+        } while (__ballot(m != 0));
       }
       {  // the last entry this pixel composited in the chunk = the highest bit of its composited mask (list order)
         const bool any = (cm[0] | cm[1]) != 0u;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
         // straight-line trips under a wave-uniform loop, two candidates per trip (as in praster_walk): a lane without a
         // candidate, or whose candidate fails the alpha tests, runs the arithmetic with alpha 0 (1 / (1 - alpha) = 1:
         // T and the running sum stay as they are) and stores nothing
-        while (__ballot(m != 0)) {
+        if (__ballot(m != 0)) do {
           const bool act = m != 0;
           const int bit0 = (__ffs((int)m) - 1) & 31;
           m &= m - 1;
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
             else if (flags)
               flags[0] = 1;
           }
-        }
+        } while (__ballot(m != 0));
       }
     }
   }

@@ -34,6 +34,6 @@ lib.gsl_g16_stats(out, 1)
 trips, valid, act, pairs, clash, lanes, kmax_sum, walked = [int(x) for x in out[:8]]
 print(f"workload R sigma {sigma}: intersections {n_is}")
 print(f"wave trips {trips} (sum over batches of the longest row list: {kmax_sum}); trips with a composited pixel {valid} "
-      f"({valid / max(trips, 1):.1%}); rows busy per trip {act / max(trips, 1):.2f} of 4")
+      f"({valid / max(trips, 1):.1%}); groups busy per trip {walked / max(trips, 1):.2f} (lists per quadrant: 4, or 8 with -DGSL_NG=8)")
 print(f"(block, entry) pairs walked {walked}; pairs with a composited pixel {pairs}; composited (pixel, entry) pairs {lanes} "
       f"({lanes / max(pairs, 1):.2f} of 16 lanes per pair)")

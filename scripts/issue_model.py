@@ -75,7 +75,7 @@ def main():
     for src, name, needle in KERNELS:
         with tempfile.TemporaryDirectory() as td:
             asm = os.path.join(td, "k.s")
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fno-slp-vectorize", "--offload-arch=gfx950", "-S", "--cuda-device-only",
                             os.path.join(ROOT, "gsplatloc_amd", "csrc", src), "-o", asm], check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             blocks = kernel_blocks(open(asm).read().splitlines(), needle)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gsplatloc_amd", "csrc")
 rows = []
 for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "--offload-arch=gfx950",
                           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
                          capture_output=True, text=True, cwd=CSRC).stderr
     cur = None

@@ -13,7 +13,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 def _resources(src):
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-c", src, "-o", os.devnull,
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fno-slp-vectorize", "--offload-arch=gfx950", "--cuda-device-only", "-c", src, "-o", os.devnull,
            "-Rpass-analysis=kernel-resource-usage"]
     res = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
