@@ -49,7 +49,9 @@ __device__ __forceinline__ int compact_quadrants(Stage& sb, int tid, bool valid_
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float cx = tile_x0 + 4.f + 8.f * (float)(q & 1), cy = tile_y0 + 4.f + 8.f * (float)(q >> 1);
-    B[q] = __ballot(valid_rec && (fabsf(x - cx) <= r + 3.5f) && (fabsf(y - cy) <= r + 3.5f));
+    // (one ballot per compare, combined as scalar masks: a ballot of a compound predicate is compiled as
+    // v_cndmask 0/1 + v_cmp_ne on top of the compares -- two more four-cycle VALU each)
+    B[q] = __ballot(valid_rec) & __ballot(fabsf(x - cx) <= r + 3.5f) & __ballot(fabsf(y - cy) <= r + 3.5f);
   }
   if (lane < 4) {
     unsigned long long b = lane == 0 ? B[0] : (lane == 1 ? B[1] : (lane == 2 ? B[2] : B[3]));
@@ -92,8 +94,8 @@ __device__ __forceinline__ void pixel_masks(int lox, int hix, int loy, int hiy, 
   (void)lane;
 #pragma unroll
   for (int v = 0; v < 8; ++v) {
-    unsigned long long mc = __ballot(lox <= v && v <= hix);
-    unsigned long long mr = __ballot(loy <= v && v <= hiy);
+    unsigned long long mc = __ballot(lox <= v) & __ballot(v <= hix);  // (not a ballot of the conjunction: see above)
+    unsigned long long mr = __ballot(loy <= v) & __ballot(v <= hiy);
     if (BLOCKROWS) {
       masked_mov2(clo, chi, mc, (0x0000111100001111ull << (v & 3)) << (16 * (v >> 2)));  // lanes of pixel column v
       masked_mov2(rlo, rhi, mr, (0x00000000000F000Full << (4 * (v & 3))) << (32 * (v >> 2)));  // lanes of pixel row v
@@ -116,6 +118,13 @@ __device__ __forceinline__ unsigned group_or(unsigned v) {
   v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
 #endif
   return v;
+}
+
+// t in the lanes of the scalar mask m, f elsewhere (v_cndmask_b32_e64 on an SGPR pair; no VCC round trip).
+__device__ __forceinline__ unsigned sel_u32(unsigned long long m, unsigned t, unsigned f) {
+  unsigned r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
 }
 
 // Index of the lowest set bit; 0xFFFFFFFF for 0 (v_ffbl_b32 as it is: __builtin_ctz(0) is undefined and __ffs costs two more
@@ -195,7 +204,10 @@ __device__ __forceinline__ void praster_walk(
         sb.s1[tid] = make_float4(0.f, 0.f, 0.f, -1.f);
       }
     }
-    int n = compact_quadrants<4>(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16));
+    // (read back from LDS: wave-uniform, but only readfirstlane tells the compiler so -- the chunk loop's control then
+    // stays on the scalar unit)
+    const int n = __builtin_amdgcn_readfirstlane(
+        compact_quadrants<4>(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16)));
     for (int c = 0; c < n; c += 64) {
       if (__all(done)) break;
       int e = c + lane;
@@ -292,15 +304,19 @@ __device__ __forceinline__ void praster_walk(
         // per pixel group (GSL_NG = 4: DPP row = 4x4 block; 8: half row = 4x2 half block): OR of the pixels'
         // composited-candidate masks; lane e then owns candidate c + e and collects its bit from the groups
         unsigned rlo = group_or(cm[0]), rhi = group_or(cm[1]);
+        // group g's OR is wave-uniform: as a scalar lane mask it IS "which lanes' candidates group g composited", so a
+        // lane picks its bit up with one select per group (no 64-bit shifts), and the union is a scalar OR, not a ballot
         unsigned nib = 0;
+        unsigned long long Rm = 0ull;
 #pragma unroll
         for (int g = 0; g < GSL_NG; ++g) {
           unsigned glo = (unsigned)__builtin_amdgcn_readlane((int)rlo, (64 / GSL_NG) * g);
           unsigned ghi = (unsigned)__builtin_amdgcn_readlane((int)rhi, (64 / GSL_NG) * g);
           unsigned long long gm = ((unsigned long long)ghi << 32) | glo;
-          nib |= (unsigned)((gm >> lane) & 1ull) << g;
+          nib |= sel_u32(gm, 1u << g, 0u);
+          Rm |= gm;
         }
-        unsigned long long Rm = __ballot(nib != 0);  // (a set bit implies e < n)
+        // (a set bit implies e < n)
         if (nib) qout[n_hits + __popcll(Rm & ((1ull << lane) - 1ull))] = (nib << GSL_HIT_SHIFT) | (unsigned)((int)bstart + (sb.qlist[wv][e] >> 4));
         n_hits += __popcll(Rm);
       }
