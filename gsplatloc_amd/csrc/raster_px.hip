@@ -126,6 +126,11 @@ __device__ __forceinline__ unsigned sel_u32(unsigned long long m, unsigned t, un
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
   return r;
 }
+__device__ __forceinline__ float sel_f32(unsigned long long m, float t, float f) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+  return r;
+}
 
 // Index of the lowest set bit; 0xFFFFFFFF for 0 (v_ffbl_b32 as it is: __builtin_ctz(0) is undefined and __ffs costs two more
 // four-cycle instructions for the zero case, which the trips below do not need).
@@ -169,8 +174,13 @@ __device__ __forceinline__ void praster_walk(
   // (block, entry) pairs and never scans an entry its quadrant did not touch
   uint32_t* const qout = isect_hits ? isect_hits + 4 * rs + (long long)wv * (re - rs) : nullptr;
   n_hits = 0;
+  // The pixels' predicates live as SCALAR lane masks from here on (round 4): each compare is one ballot, their
+  // conjunctions, negations and the running "done" set are s_and / s_andn2 / s_or on SGPR pairs, and a lane takes a
+  // value under a mask with one v_cndmask_b32_e64.  Left to the compiler, per-lane bools cost a second compare for
+  // every negation (v_cmp_nge next to v_cmp_ge) and a v_cndmask 0/1 + v_cmp_ne for every bool that crosses a loop.
+  unsigned long long DONE = __ballot(done);
   for (int b = 0; b < nb; ++b) {
-    if (__syncthreads_and(done)) break;
+    if (__syncthreads_and(DONE == ~0ull)) break;
     long long bstart = rs + (long long)b * 256;
     int bsize = (int)min((long long)256, re - bstart);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 0.f, 0.f, -1.f);
@@ -209,7 +219,7 @@ __device__ __forceinline__ void praster_walk(
     const int n = __builtin_amdgcn_readfirstlane(
         compact_quadrants<4>(sb, tid, tid < bsize, r0.x, r0.y, r1.w, (float)(txi * 16), (float)(tyi * 16)));
     for (int c = 0; c < n; c += 64) {
-      if (__all(done)) break;
+      if (DONE == ~0ull) break;
       int e = c + lane;
       int lox = 1, hix = 0, loy = 1, hiy = 0;
       if (e < n) {
@@ -221,12 +231,13 @@ __device__ __forceinline__ void praster_walk(
       }
       unsigned mlo, mhi;
       pixel_masks<true>(lox, hix, loy, hiy, lane, mlo, mhi);
-      if (done) { mlo = 0; mhi = 0; }
+      mlo = sel_u32(DONE, 0u, mlo);
+      mhi = sel_u32(DONE, 0u, mhi);
       unsigned cm[2] = {0u, 0u};  // candidates of this chunk this pixel composited
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         unsigned m = half ? mhi : mlo;
-        if (half) m = done ? 0u : m;  // (a pixel that stopped in the first half; inside the loop only m is cleared)
+        if (half) m = sel_u32(DONE, 0u, m);  // (a pixel that stopped in the first half; inside the loop only m is cleared)
         const uint16_t* const ql = &sb.qlist[wv][c + half * 32];
         // Straight-line trips under a wave-uniform loop: a lane that has run out of candidates goes through the
         // arithmetic with alpha 0.  No divergent region, so none of the copies the structurizer makes of the nine values
@@ -240,13 +251,13 @@ __device__ __forceinline__ void praster_walk(
         // list slot in front of the chunk's, some valid slot of the batch whose alpha is multiplied away) instead of
         // being selected into range; the last composited index is taken from the composited mask once per chunk, not
         // selected per trip.  72 -> 62 VALU per trip, ten of the twelve removed ones of the 4-cycle kind.
-        if (__ballot(m != 0)) do {
-          const bool act = m != 0;
+        unsigned long long ACT = __ballot(m != 0);  // lanes with a candidate left (one compare per trip: it also is
+        if (ACT) do {                                // the loop's condition)
           const unsigned b0 = m & (0u - m);
           m ^= b0;
           const unsigned b1 = m & (0u - m);
           m ^= b1;
-          const bool two = b1 != 0u;
+          const unsigned long long TWO = __ballot(b1 != 0u);
           const unsigned t0 = ql[ffbl_raw(b0)] & 0xFF0u;  // byte offsets (masked: a lane without a candidate reads
           const unsigned t1 = ql[ffbl_raw(b1)] & 0xFF0u;  // whatever sits in front of the chunk's list)
           float4 p0 = rec_at(sb.s0, t0), p1 = rec_at(sb.s1, t0);  // (x, y, a', b'), (c', opacity, r | depth, g | r_cull)
@@ -256,24 +267,29 @@ __device__ __forceinline__ void praster_walk(
           float sg1 = fmaf(u0.w * dx1, dy1, fmaf(u0.z * dx1, dx1, u1.x * dy1 * dy1));
           float al0 = fminf(GSL_ALPHA_MAX, p1.y * __builtin_amdgcn_exp2f(-sg0));
           float al1 = fminf(GSL_ALPHA_MAX, u1.y * __builtin_amdgcn_exp2f(-sg1));
-          const bool ok0 = act && sg0 >= 0.f && al0 >= GSL_ALPHA_MIN;
-          const bool ok1 = two && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN;
+          const unsigned long long OK0 = ACT & __ballot(sg0 >= 0.f) & __ballot(al0 >= GSL_ALPHA_MIN);
+          const unsigned long long OK1 = TWO & __ballot(sg1 >= 0.f) & __ballot(al1 >= GSL_ALPHA_MIN);
           if (MODE == 1) {
-            T *= 1.f - (ok0 ? al0 : 0.f);
-            T *= 1.f - (ok1 ? al1 : 0.f);
+            T *= 1.f - sel_f32(OK0, al0, 0.f);
+            T *= 1.f - sel_f32(OK1, al1, 0.f);
+            ACT = __ballot(m != 0);
             continue;
           }
-          // T > 1e-4 on entry, so a skipped candidate (alpha 0) leaves T as it is and cannot stop the pixel
-          const float a0 = ok0 ? al0 : 0.f;
-          const float nT0 = T * (1.f - a0);
-          const bool stop0 = nT0 <= GSL_T_STOP;
-          const float vis0 = stop0 ? 0.f : a0 * T;
-          const float T1 = stop0 ? T : nT0;
-          const float a1 = (ok1 && !stop0) ? al1 : 0.f;
-          const float nT1 = T1 * (1.f - a1);
-          const bool stop1 = nT1 <= GSL_T_STOP;
-          const float vis1 = stop1 ? 0.f : a1 * T1;
-          T = stop1 ? T1 : nT1;
+          // T > 1e-4 on entry, so a skipped candidate (alpha 0) leaves T as it is and cannot stop the pixel.
+          // ONE select per candidate: the alpha that takes effect is al if the candidate passes its tests and does not
+          // stop the pixel, else 0 -- and with alpha 0 the plain products give vis = 0 and T unchanged, bit for bit what
+          // selects on vis and T would (two 2-cycle ops for two 4-cycle selects per candidate).
+          const unsigned long long S0R = __ballot(T * (1.f - al0) <= GSL_T_STOP);  // candidate 0 would stop the pixel
+          const unsigned long long STOP0 = OK0 & S0R, EFF0 = OK0 & ~S0R;
+          const float a0 = sel_f32(EFF0, al0, 0.f);
+          const float vis0 = a0 * T;
+          const float T1 = T * (1.f - a0);
+          const unsigned long long LIVE1 = OK1 & ~STOP0;
+          const unsigned long long S1R = __ballot(T1 * (1.f - al1) <= GSL_T_STOP);
+          const unsigned long long STOP1 = LIVE1 & S1R, EFF1 = LIVE1 & ~S1R;
+          const float a1 = sel_f32(EFF1, al1, 0.f);
+          const float vis1 = a1 * T1;
+          T = T1 * (1.f - a1);
           if (RGB) {
             const float2 q20 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sb.s2) + t0);  // (b, depth)
             const float2 q21 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(sb.s2) + t1);
@@ -285,14 +301,14 @@ __device__ __forceinline__ void praster_walk(
             pix[D - 1] += p1.z * vis0;
             pix[D - 1] += u1.z * vis1;
           }
-          // composited <=> alpha >= 1/255 and the pixel did not stop on this entry (alpha T > 0 then: T > 1e-4); as mask
-          // logic on the compare results already there, not as two more compares of vis
-          const bool c0 = ok0 && !stop0, c1 = ok1 && !stop0 && !stop1;
-          cm[half] |= (c0 ? b0 : 0u) | (c1 ? b1 : 0u);
-          const bool stop = stop0 || stop1;
-          done = done || stop;
-          m = stop ? 0u : m;
-        } while (__ballot(m != 0));
+          // composited <=> alpha >= 1/255 and the pixel did not stop on this entry (alpha T > 0 then: T > 1e-4): the
+          // masks the alphas were selected under
+          cm[half] |= sel_u32(EFF0, b0, 0u) | sel_u32(EFF1, b1, 0u);
+          const unsigned long long STOPPED = STOP0 | STOP1;
+          DONE |= STOPPED;
+          m = sel_u32(STOPPED, 0u, m);
+          ACT = __ballot(m != 0);
+        } while (ACT);
       }
       {  // the last entry this pixel composited in the chunk = the highest bit of its composited mask (list order)
         const bool any = (cm[0] | cm[1]) != 0u;
@@ -322,6 +338,7 @@ __device__ __forceinline__ void praster_walk(
       }
     }
   }
+  done = ((DONE >> lane) & 1ull) != 0ull;
 }
 
 // lane -> pixel of the compositing kernels: wave = 8x8 quadrant, DPP row g = 4x4 block g of the quadrant, lane p of
