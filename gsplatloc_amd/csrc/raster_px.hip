@@ -766,7 +766,9 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
       r0 = GSL_Q(Q0, g);
       r1 = GSL_Q(Q1, g);
       sb.s0[tid] = r0;
-      sb.s1[tid] = r1;
+      // the conic as the FORWARD stages it (times log2 e, diagonal halved: praster_walk), so that a trip evaluates alpha
+      // with the forward's very operations and both sides take the same alpha >= 1/255 decision for every pair
+      sb.s1[tid] = make_float4(r1.x * (0.5f * GSL_LOG2E), r1.y * GSL_LOG2E, r1.z * (0.5f * GSL_LOG2E), r1.w);
       if (RGB) sb.s2[tid] = GSL_Q(Q2, g);
     } else {  // (finite numbers in every slot: see praster_walk)
       sb.id[tid] = 0;
@@ -794,28 +796,33 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         unsigned m = half ? mhi : mlo;
-        // straight-line trips under a wave-uniform loop, two candidates per trip (as in praster_walk): a lane without a
-        // candidate, or whose candidate fails the alpha tests, runs the arithmetic with alpha 0 (1 / (1 - alpha) = 1:
-        // T and the running sum stay as they are) and stores nothing
-        if (__ballot(m != 0)) do {
-          const bool act = m != 0;
-          const int bit0 = (__ffs((int)m) - 1) & 31;
-          m &= m - 1;
-          const bool two = m != 0;
-          const int bit1 = two ? __ffs((int)m) - 1 : bit0;
-          m &= m - 1;
-          const int t0 = sb.qlist[wv][c + half * 32 + bit0] & 255;
-          const int t1 = sb.qlist[wv][c + half * 32 + bit1] & 255;
+        // straight-line trips under a wave-uniform loop, two candidates per trip, candidates popped as one-bit masks,
+        // predicates as scalar lane masks (as in praster_walk): a lane without a candidate (it reads whatever slot number
+        // sits in front of the chunk's list: a valid slot, finite numbers), or whose candidate fails the alpha tests,
+        // runs the arithmetic with alpha 0 (1 / (1 - alpha) = 1: T and the running sum stay as they are) and stores
+        // nothing
+        const uint16_t* const ql = &sb.qlist[wv][c + half * 32];
+        unsigned long long ACT = __ballot(m != 0);
+        if (ACT) do {
+          const unsigned b0 = m & (0u - m);
+          m ^= b0;
+          const unsigned b1 = m & (0u - m);
+          m ^= b1;
+          const unsigned long long TWO = __ballot(b1 != 0u);
+          const int t0 = ql[ffbl_raw(b0)] & 255;
+          const int t1 = ql[ffbl_raw(b1)] & 255;
           float4 p0 = sb.s0[t0], p1 = sb.s1[t0];
           float4 u0 = sb.s0[t1], u1 = sb.s1[t1];
           float dx0 = p0.x - px, dy0 = p0.y - py, dx1 = u0.x - px, dy1 = u0.y - py;
-          float sg0 = 0.5f * (dx0 * (p1.x * dx0 + p1.y * dy0) + dy0 * (p1.y * dx0 + p1.z * dy0));
-          float sg1 = 0.5f * (dx1 * (u1.x * dx1 + u1.y * dy1) + dy1 * (u1.y * dx1 + u1.z * dy1));
-          float vis0 = __expf(-sg0), vis1 = __expf(-sg1);
+          float sg0 = fmaf(p1.y * dx0, dy0, fmaf(p1.x * dx0, dx0, p1.z * dy0 * dy0));  // log2(e) sigma, the forward's
+          float sg1 = fmaf(u1.y * dx1, dy1, fmaf(u1.x * dx1, dx1, u1.z * dy1 * dy1));  // expression
+          float vis0 = __builtin_amdgcn_exp2f(-sg0), vis1 = __builtin_amdgcn_exp2f(-sg1);
           float opv0 = p0.w * vis0, opv1 = u0.w * vis1;
           float al0 = fminf(GSL_ALPHA_MAX, opv0), al1 = fminf(GSL_ALPHA_MAX, opv1);
-          const bool ok0 = act && t0 >= t_lane && sg0 >= 0.f && al0 >= GSL_ALPHA_MIN;
-          const bool ok1 = two && t1 >= t_lane && sg1 >= 0.f && al1 >= GSL_ALPHA_MIN;
+          const unsigned long long OK0 =
+              ACT & __ballot(t0 >= t_lane) & __ballot(sg0 >= 0.f) & __ballot(al0 >= GSL_ALPHA_MIN);
+          const unsigned long long OK1 =
+              TWO & __ballot(t1 >= t_lane) & __ballot(sg1 >= 0.f) & __ballot(al1 >= GSL_ALPHA_MIN);
           float cd0 = 0.f, cd1 = 0.f;
           if constexpr (RGB) {
             float4 q20 = sb.s2[t0], q21 = sb.s2[t1];
@@ -823,9 +830,8 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
             cd1 = q21.x * vc[0] + q21.y * vc[1] + q21.z * vc[2];
           }
           if (DEPTH) { cd0 += p0.z * vc[D - 1]; cd1 += u0.z * vc[D - 1]; }
-          const float a0 = ok0 ? al0 : 0.f, a1 = ok1 ? al1 : 0.f;
-          const float ra0 = ok0 ? __builtin_amdgcn_rcpf(1.f - al0) : 1.f;
-          const float ra1 = ok1 ? __builtin_amdgcn_rcpf(1.f - al1) : 1.f;
+          const float a0 = sel_f32(OK0, al0, 0.f), a1 = sel_f32(OK1, al1, 0.f);
+          const float ra0 = __builtin_amdgcn_rcpf(1.f - a0), ra1 = __builtin_amdgcn_rcpf(1.f - a1);  // (alpha 0: exactly 1)
           const float T0 = T * ra0;
           const float fac0 = a0 * T0;
           const float va0 = T0 * cd0 - ra0 * Bp;
@@ -835,7 +841,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
           const float va1 = T1 * cd1 - ra1 * Bp0;
           T = T1;
           Bp = Bp0 + fac1 * cd1;
-          if (ok0) {
+          if (__builtin_amdgcn_inverse_ballot_w64(OK0)) {  // (exec = the mask: no per-lane test)
             float w = (opv0 <= GSL_ALPHA_MAX) ? vis0 * va0 : 0.f;
             int cc = j - tiny_origin(p0.x, p1.w), rr = i - tiny_origin(p0.y, p1.w);
             if ((unsigned)cc < 4u && (unsigned)rr < 4u)
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
             else if (flags)
               flags[0] = 1;  // sticky: the splat outgrew its 4x4 slab (r_cull >= 2 px); polled by the host
           }
-          if (ok1) {
+          if (__builtin_amdgcn_inverse_ballot_w64(OK1)) {
             float w = (opv1 <= GSL_ALPHA_MAX) ? vis1 * va1 : 0.f;
             int cc = j - tiny_origin(u0.x, u1.w), rr = i - tiny_origin(u0.y, u1.w);
             if ((unsigned)cc < 4u && (unsigned)rr < 4u)
@@ -851,7 +857,8 @@ __global__ __launch_bounds__(256) void k_tiny_bwd(
             else if (flags)
               flags[0] = 1;
           }
-        } while (__ballot(m != 0));
+          ACT = __ballot(m != 0);
+        } while (ACT);
       }
     }
   }

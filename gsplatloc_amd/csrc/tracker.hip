@@ -63,6 +63,12 @@ struct Intrin { float fx, fy, cx, cy; };
 
 template <typename F>
 __device__ __forceinline__ void surface_diffs(F img, int i, int j, int H, int W, Intrin k, float dx[3], float dy[3]) {
+  // No fused multiply-add in the differences and the cross product: the reference (torch, one kernel per operation)
+  // subtracts ROUNDED products, so on a plane facing the camera (zr == zl) yi * zr - yi * zl is exactly 0 and so is the
+  // normal's x component; fma(yi, zr, -(yi * zl)) would leave the product's rounding error there instead, and the
+  // per-row cosine of that component -- noise over noise -- moved the loss by 1e-3 (found when a compiler flag changed
+  // which of these expressions got contracted).
+#pragma clang fp contract(off)
   int jl = clampi(j - 1, 0, W - 1), jr = clampi(j + 1, 0, W - 1), iu = clampi(i - 1, 0, H - 1), id = clampi(i + 1, 0, H - 1);
   float zl = img(i, jl), zr = img(i, jr), zu = img(iu, j), zd = img(id, j);
   float yi = ((float)i - k.cy) / k.fy, xj = ((float)j - k.cx) / k.fx;
@@ -75,6 +81,7 @@ __device__ __forceinline__ void surface_diffs(F img, int i, int j, int H, int W,
 }
 
 __device__ __forceinline__ float unit_normal(const float dx[3], const float dy[3], float n[3]) {
+#pragma clang fp contract(off)  // (see surface_diffs)
   float c0 = dx[1] * dy[2] - dx[2] * dy[1], c1 = dx[2] * dy[0] - dx[0] * dy[2], c2 = dx[0] * dy[1] - dx[1] * dy[0];
   float len = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
   float inv = 1.f / fmaxf(len, 1e-12f);

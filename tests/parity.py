@@ -48,9 +48,15 @@ FLOOR32_MAX = 1.5e-3
 
 
 def pose_grad_bound(floor32: float, kind: str = "subpixel") -> float:
-    """Bound of a whole-frame pose-gradient comparison at a configuration size (relative to the largest entry)."""
-    del floor32  # (reported, bounded by FLOOR32_MAX, but no longer part of the bound: see above)
-    return POSE_GRAD_CAPS[kind]
+    """Bound of a whole-frame pose-gradient comparison at a configuration size (relative to the largest entry): the cap
+    of the configuration's kind, or 1.25 x the float32 floor measured in the same test where that is larger.
+
+    The second leg (round 4, second half): a change of instruction order in the compositing kernels -- same arithmetic,
+    bit-identical images -- moved the tracker-loss figure at T from 3.7e-4 to 9.7e-4 while the oracle's own float32 build
+    sat at 1.04e-3 from its float64 build on that configuration (the L1 loss's sign(d - g) flips wherever two depth maps
+    cross).  A float32 implementation cannot be asked to sit below the float32 floor; the floor itself stays bounded by
+    FLOOR32_MAX, so the bound never exceeds 1.9e-3, two orders below what a defect of the backward shows."""
+    return max(POSE_GRAD_CAPS[kind], 1.25 * float(floor32))
 
 
 def agreeing_pixels(render_a, alpha_a, render_b, alpha_b, rtol=IMAGE_RTOL, atol=IMAGE_ATOL):
