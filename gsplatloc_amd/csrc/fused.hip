@@ -948,6 +948,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
                                  const int32_t* order_ids, void* stream) {
   if (N < 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || ty0 < 0 || ty1 > tile_h || ty0 > ty1)
     return GSL_ERR_BAD_ARG;
+  if (N > GSL_MAX_GAUSSIANS) return GSL_ERR_BAD_ARG;  // (packed gradient rows are addressed by 32-bit byte offsets)
   if (tile_w * 16 < width || tile_h * 16 < height) return GSL_ERR_BAD_ARG;
   int n_tiles = tile_w * tile_h, nst = (ty1 - ty0) * tile_w;
   if (nst > GSL_F_MAX_STRIP_TILES) return GSL_ERR_BAD_ARG;

@@ -108,6 +108,9 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
 #endif
 #define GSL_HIT_SHIFT (32 - GSL_NG)
 #define GSL_HIT_INDEX_MASK ((1u << GSL_HIT_SHIFT) - 1u)
+// Most Gaussians one call takes: the compositing backward addresses a Gaussian's 64-byte gradient row by a 32-bit byte
+// offset (id << 6).  2^26 Gaussians are 4 GiB of rows; the largest configuration of BASELINE.json has 5 M.
+#define GSL_MAX_GAUSSIANS (1 << 26)
 // Workgroup -> work item.  Workgroups go to the eight XCDs round-robin (workgroup b runs on XCD b % 8), and every XCD has
 // its own 4 MiB L2.  With GSL_XCD_SPANS the items (tiles, in raster order) are dealt so that XCD x gets ONE contiguous
 // span of them: with the Gaussians stored in tile order (context.py:_choose_placement) the records an XCD gathers are

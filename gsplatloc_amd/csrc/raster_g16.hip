@@ -280,14 +280,14 @@ __device__ __forceinline__ void qraster_bwd_body(
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         unsigned long long Bg = __ballot(nib & (1u << g));
-        if (nib & (1u << g)) {
+        if (__builtin_amdgcn_inverse_ballot_w64(Bg)) {  // (exec = the ballot: not a second compare of the same bit)
           int q = cnt[g] + __popcll(Bg & lt);
           sb.rlist[g][q] = (uint8_t)slot;
           pack[g >> 2] |= (unsigned)q << (7 * (g & 3));
         }
         cnt[g] += __popcll(Bg);
       }
-      if (nib) {
+      if (__builtin_amdgcn_inverse_ballot_w64(R)) {
         sb.id[slot] = gid;
         sb.s0[slot] = r0;
         // the conic as the FORWARD stages it (times log2 e, diagonal halved: raster_px.hip praster_walk), so that a trip
@@ -457,8 +457,12 @@ __device__ __forceinline__ void qraster_bwd_body(
 #pragma unroll
       for (int k = 0; k < A; ++k) row[k] = 0.f;
       if (slot < staged) {
+        {  // any sum non-zero?  (one compare on the OR of the bit patterns, sign bit shifted out: -0.0 is zero)
+          unsigned bits = 0u;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) nz = nz || (mo[u][k] != 0.f);
+          for (int k = 0; k < NV; ++k) bits |= __float_as_uint(mo[u][k]);
+          nz = (bits << 1) != 0u;
+        }
         if (nz) {
           float4 r0 = sb.s0[slot], r1 = sb.s1[slot];
           float X = r0.x - tcx, Y = r0.y - tcy, S = mo[u][0];
@@ -496,8 +500,10 @@ __device__ __forceinline__ void qraster_bwd_body(
         int gi = i0 + (lane >> 4);
         if (gi < cntz && f < A) {
           int sl = sb.nzlist[gi];
-          size_t g = (size_t)sb.id[sl + 64 * u];
-          atomicAdd(&vacc[g * 16 + f], packed[sl * 16 + f]);
+          // (byte offset in 32 bits -- Gaussian ids are below 2^26, include/gsloc_hip.h -- so the atomic takes the scalar
+          // base + a 32-bit lane offset instead of three instructions of 64-bit address arithmetic)
+          const unsigned off = ((unsigned)sb.id[sl + 64 * u] << 6) | ((unsigned)f << 2);
+          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(vacc) + off), packed[sl * 16 + f]);
         }
       }
       __syncthreads();

@@ -209,6 +209,8 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     flatten_ids: the lists are the unpermuted run's lists with every id relabelled, images and
  *                     last_ids bit-identical.  Everything per Gaussian (records, vacc, v_means ...) is then in storage
  *                     order.  Not with write_sorted_keys (the deterministic backward searches the keys by id).
+ * Limits: N <= 2^26 Gaussians per call (gsl_fused_project returns GSL_ERR_BAD_ARG beyond: the compositing backward
+ *                     addresses the 64-byte gradient rows of vacc by 32-bit byte offsets).
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and
  *                     v_colors, shaped like colors) may be NULL together (pose-only);
  *                     v_viewmat[16] is overwritten (row 3 = 0).  tiny_trec / tiny_vcT (may be NULL): the slabs
