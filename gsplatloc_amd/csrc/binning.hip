@@ -368,7 +368,7 @@ __device__ __forceinline__ void wave_sort_tile(const uint64_t* __restrict__ src,
   uint64_t k[KPT];
   int e0 = lane * KPT;
 #pragma unroll
-  for (int r = 0; r < KPT; ++r) k[r] = (r * 64 + lane < n) ? src[r * 64 + lane] : ~0ull;
+  for (int r = 0; r < KPT; ++r) k[r] = (r * 64 + lane < n) ? src[r * 64 + lane] : GSL_SORT_PAD;
   wave_sort_regs<LK>(k, lane);
   if (LK <= 4 && !isect_ids && !keys_out) {  // (32 keys per lane: the ids' registers would cost the instance a wave per SIMD)
 #pragma unroll
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void k_long_sort_seg(const int32_t* __restrict_
   constexpr int KPL = GSL_SORT_SEG / 64;  // keys per lane
   uint64_t k[KPL];
 #pragma unroll
-  for (int r = 0; r < KPL; ++r) k[r] = (lane * KPL + r < m) ? src[lane * KPL + r] : ~0ull;
+  for (int r = 0; r < KPL; ++r) k[r] = (lane * KPL + r < m) ? src[lane * KPL + r] : GSL_SORT_PAD;
   wave_sort_regs<GSL_SORT_SEG_LOG2 - 6>(k, lane);
   uint64_t* dst = keys + s + (size_t)sgm * GSL_SORT_SEG;
 #pragma unroll

@@ -962,6 +962,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
   hipStream_t st = (hipStream_t)stream;
   int32_t* counts = (int32_t*)ws;
   int32_t* cursors = counts + n_tiles;
+  GSL_CLAMP_DEPTH_WINDOW(near_plane, far_plane);
   // binned mode relies on the scan leaving the counters cleared (ws zero-filled once by the caller): no clearing launch
   if (!bins && gsl::zero_u32(counts, (size_t)n_tiles, st) != GSL_OK) return GSL_ERR_HIP;
   if (N > 0) {

@@ -108,6 +108,14 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
 #endif
 #define GSL_HIT_SHIFT (32 - GSL_NG)
 #define GSL_HIT_INDEX_MASK ((1u << GSL_HIT_SHIFT) - 1u)
+// Depths that reach the sort keys are positive, finite, normal floats: the window [near_plane, far_plane] of a projection
+// is clamped to [FLT_MIN, FLT_MAX] on the host (a Gaussian at z <= 0 has no perspective projection anyway; the reference
+// calls with near_plane = 0.01).  The per-tile sorts compare keys as doubles on that ground (sort_dev.h cswap).
+#define GSL_CLAMP_DEPTH_WINDOW(nearp, farp)            \
+  do {                                                 \
+    if (!((nearp) >= 1.17549435e-38f)) (nearp) = 1.17549435e-38f; \
+    if (!((farp) <= 3.40282347e+38f)) (farp) = 3.40282347e+38f;   \
+  } while (0)
 // Most Gaussians one call takes: the compositing backward addresses a Gaussian's 64-byte gradient row by a 32-bit byte
 // offset (id << 6).  2^26 Gaussians are 4 GiB of rows; the largest configuration of BASELINE.json has 5 M.
 #define GSL_MAX_GAUSSIANS (1 << 26)

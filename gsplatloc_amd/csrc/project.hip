@@ -151,6 +151,7 @@ extern "C" int gsl_project_fwd(const float* means, const float* quats, const flo
   if (!means || !quats || !scales || !viewmat || !K || !radii || !means2d || !depths || !conics)
     return GSL_ERR_BAD_ARG;
   int grid = (N + 255) / 256;
+  GSL_CLAMP_DEPTH_WINDOW(near_plane, far_plane);
   hipLaunchKernelGGL(gsl::k_project_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, means, quats, scales,
                      viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip, radii, means2d, depths,
                      conics, compensations);

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SORT == 3 ?
       const uint64_t* src = fs.bins + (size_t)tile * (size_t)fs.bin_cap;
       uint64_t k[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) k[r] = (lane * 4 + r < n) ? src[lane * 4 + r] : ~0ull;
+      for (int r = 0; r < 4; ++r) k[r] = (lane * 4 + r < n) ? src[lane * 4 + r] : GSL_SORT_PAD;
       wave_sort_regs<2>(k, lane);
 #pragma unroll
       for (int r = 0; r < 4; ++r)

@@ -22,11 +22,22 @@ __device__ __forceinline__ unsigned sort_sel(unsigned long long m, unsigned t, u
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
   return r;
 }
-__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {  // a <- min, b <- max
-  const unsigned long long sw = __ballot(a > b);
-  const unsigned alo = (unsigned)a, ahi = (unsigned)(a >> 32), blo = (unsigned)b, bhi = (unsigned)(b >> 32);
-  a = ((uint64_t)sort_sel(sw, bhi, ahi) << 32) | sort_sel(sw, blo, alo);
-  b = ((uint64_t)sort_sel(sw, ahi, bhi) << 32) | sort_sel(sw, alo, blo);
+// Compare-exchange of two keys held in one lane: a <- min, b <- max.
+// A key is (depth bits << 32) | Gaussian index with the depth a POSITIVE FINITE float (every projection of this library
+// culls z <= 0 and z > far_plane), so its 64 bits read as a double are a positive finite double, and positive doubles
+// order like their bit patterns: v_min_f64 / v_max_f64 return the smaller / larger KEY, bit for bit (they return one of
+// their operands; no NaN, no -0 here).  Two instructions per compare-exchange instead of one 64-bit compare + four
+// selects; all of them issue at the same rate on gfx950 (scripts/ubench/valu.hip kinds 93-99: 1.9 ns), so the in-register
+// stages of the network cost 2/5 of what they did.  The padding key of a short list is GSL_SORT_PAD = +infinity (hi word
+// 0x7FF00000: above every finite float's bits); ~0 would be a NaN, which min AND max both drop.
+#define GSL_SORT_PAD 0x7FF0000000000000ull
+__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {
+  const double x = __longlong_as_double((long long)a), y = __longlong_as_double((long long)b);
+  double lo, hi;
+  asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+  asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+  a = (uint64_t)__double_as_longlong(lo);
+  b = (uint64_t)__double_as_longlong(hi);
 }
 // keep_min_mask: ballot of the lanes that keep the smaller key of (a, partner's o)
 __device__ __forceinline__ uint64_t pick(uint64_t a, uint64_t o, unsigned long long keep_min_mask) {
@@ -180,7 +191,7 @@ __device__ __forceinline__ void wg_sort_tile(const uint64_t* __restrict__ src, i
   uint64_t k[KPT];
   const int e0 = wv * RUN + lane * KPT;
 #pragma unroll
-  for (int r = 0; r < KPT; ++r) k[r] = (e0 + r < n) ? src[e0 + r] : ~0ull;
+  for (int r = 0; r < KPT; ++r) k[r] = (e0 + r < n) ? src[e0 + r] : GSL_SORT_PAD;
   wave_sort_regs<LK>(k, lane);
   uint64_t* bufA = lds;
   uint64_t* bufB = lds + 4 * RUN;

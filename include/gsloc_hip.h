@@ -209,6 +209,11 @@ int gsl_vacc_unpack(const float* vacc, int n_gaussians, int channels, float* v_m
  *                     flatten_ids: the lists are the unpermuted run's lists with every id relabelled, images and
  *                     last_ids bit-identical.  Everything per Gaussian (records, vacc, v_means ...) is then in storage
  *                     order.  Not with write_sorted_keys (the deterministic backward searches the keys by id).
+ * Sort keys: (depth bits << 32) | Gaussian index, the depth a positive finite normal float -- gsl_fused_project and
+ *                     gsl_project_fwd clamp their depth window to [FLT_MIN, FLT_MAX], so every key this library makes is
+ *                     one; the per-tile sorts (gsl_fused_bin, gsl_tile_sort_keys, gsl_long_sort, the sorting forward)
+ *                     compare keys as doubles on that ground and order other bit patterns differently from an unsigned
+ *                     compare (depths handed to the stage-wise isect entry points must be positive and finite).
  * Limits: N <= 2^26 Gaussians per call (gsl_fused_project returns GSL_ERR_BAD_ARG beyond: the compositing backward
  *                     addresses the 64-byte gradient rows of vacc by 32-bit byte offsets).
  * gsl_fused_project_bwd : consumes AND CLEARS vacc; v_means/v_quats/v_scales/v_opacities (and

@@ -117,6 +117,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float sv) {
         if (KIND == 90) asm volatile("v_xad_u32 %0, %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
         if (KIND == 91) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));
         if (KIND == 92) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[i]) : "v"(u[(i + 1) & 7]));
+        // fourth batch (round 4): 64-bit compare / min / max for sort keys held as register pairs
+        if (KIND == 93) asm volatile("v_min_f64 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        if (KIND == 94) asm volatile("v_max_f64 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        if (KIND == 95) asm volatile("v_cmp_gt_u64_e64 s[20:21], %0, %1" :: "v"(p[i]), "v"(p[(i + 1) & 7]) : "s20", "s21");
+        if (KIND == 96) asm volatile("v_cmp_lt_f64_e64 s[20:21], %0, %1" :: "v"(p[i]), "v"(p[(i + 1) & 7]) : "s20", "s21");
+        if (KIND == 97) asm volatile("v_mov_b64 %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        if (KIND == 98) asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(u[i]) : "v"(laddr & 252u));
+        if (KIND == 99) asm volatile("v_cmp_gt_u32_e64 s[20:21], %0, %1" :: "v"(u[i]), "v"(u[(i + 1) & 7]) : "s20", "s21");
         if (KIND == 34) { float4 q; asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"(lbase)); if (i == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a[0] += q.x; } }
         if (KIND == 35) { float q; asm volatile("ds_read_u8 %0, %1" : "=v"(q) : "v"(laddr)); if (i == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a[0] += q; } }
         if (KIND == 36) { float4 q; asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"(lrand)); if (i == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); a[0] += q.x; } }
@@ -142,9 +150,13 @@ template <int KIND> void run(const char* name, float* d, int blocks_per_cu) {
   printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f ns/instr/SIMD, in-kernel %.2f cyc/instr/SIMD (memtime clk)\n", name, blocks_per_cu, ms,
          ms * 1e6 / winstr_per_simd, cyc / ((double)iters * REP * blocks_per_cu));
 }
-int main() {
+int main(int argc, char** argv) {
   float* d; (void)hipMalloc(&d, 256 * 8 * 256 * 4 + 1024);
   for (int b : {2, 8}) {
+    run<93>("v_min_f64", d, b); run<94>("v_max_f64", d, b); run<95>("v_cmp_gt_u64 ->sgpr", d, b); run<96>("v_cmp_lt_f64 ->sgpr", d, b);
+    run<97>("v_mov_b64", d, b); run<98>("ds_bpermute_b32 + wait", d, b); run<99>("v_cmp_gt_u32 ->sgpr", d, b);
+    run<0>("v_fma_f32 vvv", d, b); run<8>("v_cndmask e64 sgprpair", d, b); run<28>("v_mov_b32_dpp quad_perm", d, b);
+    if (argc > 1) continue;  // "valu.bin new": the fourth batch and three anchors only
     run<0>("v_fma_f32 vvv", d, b); run<1>("v_fma_f32 sgpr", d, b); run<2>("v_exp_f32", d, b); run<3>("v_readlane_b32", d, b);
     run<4>("v_cndmask vcc", d, b); run<5>("v_cmp_e64 ->sgpr", d, b); run<6>("v_add_f32", d, b); run<7>("v_mul_f32", d, b);
     run<8>("v_cndmask e64 sgprpair", d, b); run<9>("v_min_f32", d, b); run<10>("v_add_f32_dpp", d, b); run<11>("v_cndmask vcc 2src", d, b);
