@@ -65,7 +65,13 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
   if (BINNED && bin_state && nst > 0 && blockIdx.x == 0 && threadIdx.x == 0) {
     if (atomicExch(bin_state, 1) != 0 && flags) flags[3] = 1;
   }
+  // s_hist[nst], s_hist[nst + 1]: lowest / highest strip-tile index a Gaussian of this workgroup touches.  The passes over
+  // the counters below cover that range only: with the Gaussians stored in tile order (context.py:_choose_placement) a
+  // workgroup's 512 touch a band of two or three tile rows, not the frame's 3 225 tiles (the fixed 16-step loops were a
+  // quarter of the kernel's VALU instructions).
+  int* const s_rng = s_hist + nst;
   for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) s_hist[k] = 0;
+  if (threadIdx.x == 0) { s_rng[0] = nst; s_rng[1] = -1; }
   __syncthreads();
   int i = blockIdx.x * GSL_F_BIN_THREADS + threadIdx.x;
   Cam cam = load_cam(V, Kmat);
@@ -145,11 +151,22 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
     }
     if (tiles_per_gauss) tiles_per_gauss[i] = (xmax - xmin) * (ymax - ymin);
   }
+  {
+    const bool has = (ymin < ymax) && (xmin < xmax);
+    int lo = has ? ymin * tile_w + xmin - tbase : nst, hi = has ? (ymax - 1) * tile_w + (xmax - 1) - tbase : -1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, 64));
+      hi = max(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && hi >= 0) { atomicMin(&s_rng[0], lo); atomicMax(&s_rng[1], hi); }
+  }
   for (int y = ymin; y < ymax; ++y)
     for (int x = xmin; x < xmax; ++x) atomicAdd(&s_hist[y * tile_w + x - tbase], 1);
   __syncthreads();
+  const int k_lo = __builtin_amdgcn_readfirstlane(s_rng[0]), k_hi = __builtin_amdgcn_readfirstlane(s_rng[1]);
   if (!BINNED) {
-    for (int k = threadIdx.x; k < nst; k += GSL_F_BIN_THREADS) {
+    for (int k = k_lo + (int)threadIdx.x; k <= k_hi; k += GSL_F_BIN_THREADS) {
       int c = s_hist[k];
       if (c) atomicAdd(&tile_counts[tbase + k], c);
     }
@@ -159,14 +176,19 @@ __global__ __launch_bounds__(GSL_F_BIN_THREADS) void k_fproject(
   int res[GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS];
 #pragma unroll
   for (int u = 0; u < GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS; ++u) {
-    int k = threadIdx.x + u * GSL_F_BIN_THREADS;
-    int c = (k < nst) ? s_hist[k] : 0;
-    res[u] = c ? atomicAdd(&tile_counts[tbase + k], c) : 0;
+    res[u] = 0;
+    if (k_lo + u * GSL_F_BIN_THREADS <= k_hi) {  // (wave-uniform)
+      int k = k_lo + (int)threadIdx.x + u * GSL_F_BIN_THREADS;
+      int c = (k <= k_hi) ? s_hist[k] : 0;
+      res[u] = c ? atomicAdd(&tile_counts[tbase + k], c) : 0;
+    }
   }
 #pragma unroll
   for (int u = 0; u < GSL_F_MAX_STRIP_TILES / GSL_F_BIN_THREADS; ++u) {
-    int k = threadIdx.x + u * GSL_F_BIN_THREADS;
-    if (k < nst && s_hist[k]) s_hist[k] = res[u];  // first slot of this workgroup's span; ranks count up from it
+    if (k_lo + u * GSL_F_BIN_THREADS <= k_hi) {
+      int k = k_lo + (int)threadIdx.x + u * GSL_F_BIN_THREADS;
+      if (k <= k_hi && s_hist[k]) s_hist[k] = res[u];  // first slot of this workgroup's span; ranks count up from it
+    }
   }
   __syncthreads();
   for (int y = ymin; y < ymax; ++y)
@@ -967,7 +989,7 @@ extern "C" int gsl_fused_project(const float* means, const float* quats, const f
   if (!bins && gsl::zero_u32(counts, (size_t)n_tiles, st) != GSL_OK) return GSL_ERR_HIP;
   if (N > 0) {
     dim3 grid((N + GSL_F_BIN_THREADS - 1) / GSL_F_BIN_THREADS), block(GSL_F_BIN_THREADS);
-    size_t lds = (size_t)(nst > 0 ? nst : 1) * sizeof(int);
+    size_t lds = (size_t)(nst + 2) * sizeof(int);  // counters + the touched range
 #define CALL_P(RGBV, BINV)                                                                                            \
   hipLaunchKernelGGL((gsl::k_fproject<RGBV, BINV>), grid, block, lds, st, means, quats, scales, opacities, colors,    \
                      sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near_plane, far_plane, radius_clip,        \
