@@ -246,7 +246,9 @@ def issue_bound(stage, launch_ms):
     if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_BUSY_CYCLES_per_se") and valu:
         out["valu_busy_frac"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / (simds * sq["SQ_BUSY_CYCLES_per_se"])
         out["cycles_per_valu_inst"] = sq["SQ_ACTIVE_INST_VALU"] * 4.0 / valu
-        out["frac"] = out["valu_busy_frac"]
+        # (two counters of different blocks: the ratio is good to a few per cent -- the forward of round 4's last build
+        # reads 1.04 -- so `frac` saturates at 1 and the raw ratio stays next to it)
+        out["frac"] = min(1.0, out["valu_busy_frac"])
     return out
 
 

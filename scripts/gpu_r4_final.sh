@@ -11,5 +11,6 @@ r = d["roofline"]
 print(d["ms_per_step"], d["value"], "frac", r["frac"], "traffic", r["traffic"], "issue frac", r.get("issue", {}).get("frac"), "cpu", d["cpu_baseline"]["value"])
 PY
 bash scripts/gpu_r4_trk.sh
+timeout -k 10 300 python scripts/trk_render_mode.py 2>/dev/null | tee gpurun_out/r04_tracker_render_mode.txt
 ( timeout -k 10 300 python scripts/strip_scaling.py 1.0 random R; timeout -k 10 400 python scripts/strip_scaling.py 1.0 random X ) > gpurun_out/r04_strip_scaling_estimate.txt 2>&1
 grep "^world" gpurun_out/r04_strip_scaling_estimate.txt
