@@ -750,18 +750,28 @@ __global__ __launch_bounds__(256) void k_fproject_bwd(
   __shared__ float4 srow[256][3];
   if (trec) {
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-      int t = pass * 256 + threadIdx.x;
-      int lg = t >> 2, r = t & 3, gid = blockIdx.x * 256 + lg;
-      bool lv = gid < N && radii[gid] > 0;
-      float v[6 + D];
-      tiny_fold_slab<D>(Q0, Q1, W, H, trec, vcT, gid, r, lv, v);
-      float pad[12];
+    for (int half = 0; half < 2; ++half) {  // two (Gaussian, slab row) items per turn: their loads leave together
+      TinySlabIn in[2];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) pad[k] = (k < 6 + D) ? v[k] : 0.f;
-      if (r == 0) srow[lg][0] = make_float4(pad[0], pad[1], pad[2], pad[3]);
-      if (r == 1) srow[lg][1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
-      if (r == 2) srow[lg][2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
+      for (int u = 0; u < 2; ++u) {
+        int t = (2 * half + u) * 256 + threadIdx.x;
+        in[u] = tiny_slab_load(radii, Q0, Q1, trec, blockIdx.x * 256 + (t >> 2), t & 3, N);
+      }
+      GSL_TINY_SLAB_PIN(in[0]);
+      GSL_TINY_SLAB_PIN(in[1]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        int t = (2 * half + u) * 256 + threadIdx.x;
+        int lg = t >> 2, r = t & 3, gid = blockIdx.x * 256 + lg;
+        float v[6 + D];
+        tiny_slab_fold<D>(in[u], W, H, trec, vcT, gid, r, v);
+        float pad[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pad[k] = (k < 6 + D) ? v[k] : 0.f;
+        if (r == 0) srow[lg][0] = make_float4(pad[0], pad[1], pad[2], pad[3]);
+        if (r == 1) srow[lg][1] = make_float4(pad[4], pad[5], pad[6], pad[7]);
+        if (r == 2) srow[lg][2] = make_float4(pad[8], pad[9], pad[10], pad[11]);
+      }
     }
     __syncthreads();
   }

@@ -644,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_long_combine(int W, int H, int tile_w,
 // (pixel, splat) it stores  (w, fac) = (vis * v_alpha [0 when alpha is clamped], alpha * T)  into the
 // splat's own 4x4 slab  trec[g][row - r0][col - c0]  (plain 8-byte stores, no atomics, no reduction), and
 // every pixel leaves its (expected-depth-chained) upstream gradient in vcT[H,W,D].
-// Pass 2 runs inside the projection backward (k_fproject_bwd, tiny_fold_slab in gsloc_common.h): four lanes per
+// Pass 2 runs inside the projection backward (k_fproject_bwd, tiny_slab_load + tiny_slab_fold in gsloc_common.h): four lanes per
 // Gaussian read its slab, rebuild dx, dy from the Gaussian's own record and sum the 16 slots into its gradient row,
 // which never leaves LDS.
 // ---------------------------------------------------------------------------------------------------
