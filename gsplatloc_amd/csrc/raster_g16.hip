@@ -511,30 +511,25 @@ __device__ __forceinline__ void qraster_bwd_body(
   }
 }
 
+// One work item: a (tile, quadrant) pair, or LONG a (segment slot, quadrant) pair.  b = the item's index of n_items.
 template <int D, bool ED, int CG, bool LONG>
-__global__ __launch_bounds__(64) void k_qraster_bwd(
-    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
-    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
-    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-    float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
+__device__ __forceinline__ void qraster_bwd_item(
+    QStage<D, CG>& sb, int b, int n_items, const float4* __restrict__ Q0, const float4* __restrict__ Q1,
+    const float4* __restrict__ Q2, int W, int H, int tile_w, int ty0, const int32_t* __restrict__ tile_offsets,
+    const int32_t* __restrict__ flatten_ids, long long capacity, const float* __restrict__ render,
+    const float* __restrict__ alphas, const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
+    const float* __restrict__ v_alphas, float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
     const uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts, int long_min, LongWs lw,
     int32_t* __restrict__ rgb_flag, int32_t* __restrict__ clear_counts, int32_t* __restrict__ clear_state) {
-  __shared__ QStage<D, CG> sb;
   // (a forward that sorted its own bins could not clear the tile counters, raster_px.hip k_praster_fwd SORT: the first
   // launch of the backward does, one lane per tile)
-  if (!LONG && (CG == 1 || D == 3) && clear_counts && (blockIdx.x & 3) == 0 && threadIdx.x == 0) {
-    clear_counts[ty0 * tile_w + (blockIdx.x >> 2)] = 0;  // (any one-to-one map of workgroups to tiles does for clearing)
-    if (blockIdx.x == 0 && clear_state) *clear_state = 0;
+  if (!LONG && (CG == 1 || D == 3) && clear_counts && (b & 3) == 0 && threadIdx.x == 0) {
+    clear_counts[ty0 * tile_w + (b >> 2)] = 0;  // (any one-to-one map of items to tiles does for clearing)
+    if (b == 0 && clear_state) *clear_state = 0;
   }
-  // rgb_flag (may be NULL; D = 4 only): raised by the depth-only kernel when it leaves a quadrant to the full-colour
-  // kernel, cleared by the compositing forward.  The full-colour launch returns on a clear flag after one load per
-  // workgroup instead of reading its 64 pixels' upstream gradient to find out that it has nothing to do (GsplatLoc's
-  // loss: always).  A stale raised flag (a second backward after the same forward) only costs that reading.
-  if (D == 4 && CG == D && rgb_flag && *rgb_flag == 0) return;
   // (LONG: items are (tile, segment) slots; otherwise the (tile, quadrant) pairs are dealt to the XCDs in contiguous
   // spans: gsloc_common.h)
-  const int wi = LONG ? (int)blockIdx.x : xcd_span_item((int)blockIdx.x, (int)gridDim.x);
+  const int wi = LONG ? b : xcd_span_item(b, n_items);
   const int quad = wi & 3, item = wi >> 2;
   int tile, sgm = 0, gseg = 0;
   if (LONG) {
@@ -645,6 +640,33 @@ __global__ __launch_bounds__(64) void k_qraster_bwd(
                           (float)(tyi * 16), bin_final, T_init, Bp_init, vc, qh, nqh);
 }
 
+// One wave per workgroup.  The grid is one workgroup per item for every launch but the full-colour second one of
+// "RGB+ED" (CG = D = 4), which gets a capped grid whose workgroups walk the items with a stride: that launch finds its
+// flag clear on every iteration of GsplatLoc's loss, and 12 900 workgroups that load one word and leave cost 4.4 us
+// against 1.5 for 2 048.
+template <int D, bool ED, int CG, bool LONG>
+__global__ __launch_bounds__(64) void k_qraster_bwd(
+    const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
+    int tile_w, int ty0, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+    long long capacity, const float* __restrict__ render, const float* __restrict__ alphas,
+    const int32_t* __restrict__ last_ids, const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+    float* __restrict__ vacc, int row0, int row1, const uint4* __restrict__ Qh,
+    const uint32_t* __restrict__ isect_hits, int32_t* __restrict__ isect_hit_counts, int long_min, LongWs lw,
+    int32_t* __restrict__ rgb_flag, int32_t* __restrict__ clear_counts, int32_t* __restrict__ clear_state, int n_items) {
+  __shared__ QStage<D, CG> sb;
+  // rgb_flag (may be NULL; D = 4 only): raised by the depth-only kernel when it leaves a quadrant to the full-colour
+  // kernel, cleared by the compositing forward.  The full-colour launch returns on a clear flag after one load per
+  // workgroup instead of reading its 64 pixels' upstream gradient to find out that it has nothing to do (GsplatLoc's
+  // loss: always).  A stale raised flag (a second backward after the same forward) only costs that reading.
+  if (D == 4 && CG == D && rgb_flag && *rgb_flag == 0) return;
+  for (int b = (int)blockIdx.x; b < n_items; b += (int)gridDim.x) {
+    qraster_bwd_item<D, ED, CG, LONG>(sb, b, n_items, Q0, Q1, Q2, W, H, tile_w, ty0, tile_offsets, flatten_ids, capacity,
+                                      render, alphas, last_ids, v_render, v_alphas, vacc, row0, row1, Qh, isect_hits,
+                                      isect_hit_counts, long_min, lw, rgb_flag, clear_counts, clear_state);
+    __syncthreads();  // (the next item stages into the same LDS)
+  }
+}
+
 }  // namespace gsl
 
 #ifdef GSL_G16_STATS
@@ -681,16 +703,18 @@ extern "C" int gsl_g16_raster_bwd_launch(const float* Q0, const float* Q1, const
   int32_t* clear_state = clear_ws ? gsl_fused_bin_state(clear_ws, rgb_flag_index / 4) : nullptr;  // (4 n_tiles)
 #define CALL_Q(DD, EE, CC)                                                                                   \
   do {                                                                                                       \
+    const int n_items = 4 * nblk;                                                                            \
+    const int grid = ((DD) == 4 && (CC) == 4 && rgb_flag && n_items > 2048) ? 2048 : n_items;                \
     if (lng)                                                                                                 \
-      hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, true>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
+      hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, true>), dim3(grid), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag, clear_counts, clear_state);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag, clear_counts, clear_state, n_items);                   \
     else                                                                                                     \
-      hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, false>), dim3(4 * nblk), dim3(64), 0, st, (const float4*)Q0, \
+      hipLaunchKernelGGL((gsl::k_qraster_bwd<DD, EE, CC, false>), dim3(grid), dim3(64), 0, st, (const float4*)Q0, \
                          (const float4*)Q1, (const float4*)Q2, width, height, tile_w, ty0, tile_offsets,     \
                          flatten_ids, (long long)capacity, render, alphas, last_ids, v_render, v_alphas, vacc, \
-                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag, clear_counts, clear_state);                            \
+                         row0, row1, (const uint4*)Qh, isect_hits, const_cast<int32_t*>(isect_hit_counts), long_min, lw, rgb_flag, clear_counts, clear_state, n_items);                   \
   } while (0)
   if (channels == 1) { if (ed) CALL_Q(1, true, 1); else CALL_Q(1, false, 1); }
   else if (channels == 3) { CALL_Q(3, false, 3); }
