@@ -51,6 +51,12 @@ def test_bad_arguments_are_rejected_without_a_gpu():
                                  None, None) == -1
     assert lib.gsl_isect_count(None, None, 0, 16, 4, 3, 0, 4, None, None, None, None, 0, None) == -1  # ty1 > tile_h
     assert lib.gsl_sh_fwd(4, None, None, None, 1, 25, None, None) == -1
+    # more Gaussians than the packed gradient rows can address with 32-bit byte offsets (include/gsloc_hip.h, "Limits"):
+    # means, quats, scales, opacities, colors, sh_degree, K_sh, viewmat, K, N, width, height, eps2d, near, far,
+    # radius_clip, antialiased, tile_w, tile_h, ty0, ty1, then 17 pointers / sizes
+    assert lib.gsl_fused_project(None, None, None, None, None, 1, 4, None, None, (1 << 26) + 1, 64, 48, 0.3, 0.01, 1e10,
+                                 0.0, 0, 4, 3, 0, 3, None, None, None, None, None, None, None, None, None, 0, None, None,
+                                 0, None, None, None) == -1
     assert lib.gsl_project_bwd_ws_bytes(1000) == 4 * 12 * 4
     assert lib.gsl_isect_ws_bytes(100) == 800
 

@@ -760,6 +760,43 @@ def test_hip_frustum_clamp_branches():
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9
 
 
+@pytest.mark.gpu
+def test_a_non_positive_near_plane_is_clamped_to_the_smallest_normal_depth():
+    """The per-tile sorts compare (depth bits, index) keys as doubles, which holds for positive finite normal depths; the
+    projection entry points clamp the depth window to [FLT_MIN, FLT_MAX] (include/gsloc_hip.h, "Sort keys").  A scene with
+    Gaussians behind the camera rendered with near_plane = -1 must equal the render with near_plane = FLT_MIN bit for bit
+    (nothing at z <= 0 is projected), and every tile list must come out ascending in (depth, index)."""
+    import gsplatloc_amd as A
+    g = torch.Generator().manual_seed(11)
+    N, W, H = 3000, 160, 120
+    means = torch.rand(N, 3, generator=g) * torch.tensor([4.0, 3.0, 6.0]) - torch.tensor([2.0, 1.5, 2.0])  # z in [-2, 4]
+    quats = torch.tensor([1.0, 0, 0, 0]).repeat(N, 1)
+    scales = torch.full((N, 3), 0.03)
+    opac = torch.full((N,), 0.8)
+    rgbs = torch.rand(N, 3, generator=g)
+    K = torch.tensor([[120.0, 0, 79.5], [0, 120.0, 59.5], [0, 0, 1]])
+    V = torch.eye(4)
+    outs = {}
+    for near in (-1.0, 1.17549435e-38):
+        r, a, meta = A.rasterization(means.cuda(), quats.cuda(), scales.cuda(), opac.cuda(), rgbs.cuda(), viewmats=V.cuda()[None],
+                                     Ks=K.cuda()[None], width=W, height=H, near_plane=near, render_mode="RGB+ED", packed=False,
+                                     sh_degree=None)
+        total = int(meta["tiles_per_gauss"].sum())
+        outs[near] = (r.cpu(), a.cpu(), meta["radii"][0].cpu(), meta["flatten_ids"][:total].cpu(),
+                      meta["isect_offsets"].cpu(), meta["depths"][0].cpu())
+    a, b = outs[-1.0], outs[1.17549435e-38]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    radii, fids, offs, depths = a[2], a[3].long(), a[4].reshape(-1).long(), a[5]
+    assert int((radii[means[:, 2] <= 0] > 0).sum()) == 0 and int((radii > 0).sum()) > 500
+    ends = torch.cat([offs[1:], torch.tensor([fids.numel()])])
+    for s0, e0 in zip(offs.tolist(), ends.tolist()):
+        d = depths[fids[s0:e0]]
+        key = (d.view(torch.int32).long() << 32) | fids[s0:e0]
+        assert bool((key[1:] > key[:-1]).all())
+
+
+@pytest.mark.gpu
 def test_wide_features_are_composited_in_channel_chunks():
     """gsplat.rasterization with more feature channels than one compositing kernel takes (32 feature
     channels + the depth channel of RGB+ED = 33): the general path splits the channels into chunks of channel_chunk,
