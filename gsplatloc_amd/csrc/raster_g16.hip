@@ -642,8 +642,8 @@ __device__ __forceinline__ void qraster_bwd_item(
 
 // One wave per workgroup.  The grid is one workgroup per item for every launch but the full-colour second one of
 // "RGB+ED" (CG = D = 4), which gets a capped grid whose workgroups walk the items with a stride: that launch finds its
-// flag clear on every iteration of GsplatLoc's loss, and 12 900 workgroups that load one word and leave cost 4.4 us
-// against 1.5 for 2 048.
+// flag clear on every iteration of GsplatLoc's loss, and 12 900 workgroups that load one word and leave cost the graph
+// about 2.5 us more than 2 048 do (the stage of both backward launches at R: 184 -> 181.6 us).
 template <int D, bool ED, int CG, bool LONG>
 __global__ __launch_bounds__(64) void k_qraster_bwd(
     const float4* __restrict__ Q0, const float4* __restrict__ Q1, const float4* __restrict__ Q2, int W, int H,
