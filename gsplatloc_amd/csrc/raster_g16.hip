@@ -156,7 +156,13 @@ __device__ unsigned long long g16_stats[8];
 #endif
 
 #ifndef GSL_QB
-#define GSL_QB 95    // staged entries per batch of one quadrant (measured at R: 64: 273 us, 95: 257, 111: 269, 127: 264)
+// Staged entries per batch of one quadrant.  Round 3 (the wave scanned the tile's whole list and kept what its quadrant
+// touched): 64: 273 us at R, 95: 257, 111: 269, 127: 264.  With the forward's hit lists every scanned entry is staged, a
+// scan step is 64 entries and "room for a whole step" made every batch 64 entries whatever the capacity above that -- the
+// slots 64..94 only cost LDS (8.4 -> 7.1 KB per wave, 19 -> 23 workgroups per CU): R 182 -> 179 us, X 437 -> 411.  (Filling
+// 95-entry batches with a second, partial step was measured too: 198 us -- the gather and the flush run half empty on
+// slots 64..94.)  Without hit lists (a caller that passes none) a batch is what one step of 64 list entries yields.
+#define GSL_QB 64
 #endif
 #define GSL_QBS (GSL_QB + 1)  // + the sentinel slot
 #ifndef GSL_Q_LCAP
