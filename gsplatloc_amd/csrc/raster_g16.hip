@@ -166,7 +166,10 @@ __device__ unsigned long long g16_stats[8];
 #endif
 #define GSL_QBS (GSL_QB + 1)  // + the sentinel slot
 #ifndef GSL_Q_LCAP
-#define GSL_Q_LCAP 32
+// Trips per list per round (the pair slots of a round: 4 lists x LCAP x 8 floats).  24: 3 KB, what the 64 packed gradient
+// rows of the flush need anyway (12-float pitch); the wave's LDS is then 6.1 KB and the registers (78) set the occupancy
+// at 6 waves per SIMD.  32 / 40 / 48 measured at R: 178 / 179 / 189 us, 24: 177 (X: 402 / 432 / 458, 24: 392).
+#define GSL_Q_LCAP 24
 #endif
 
 template <int D, int CG>
@@ -200,7 +203,8 @@ __device__ __forceinline__ void qraster_bwd_body(
   constexpr int A = QStage<D, CG>::A;
   constexpr int LCAP = QStage<D, CG>::LCAP;
   constexpr int NG = G16_NG, GL = G16_GL;
-  static_assert(NG * LCAP * NS >= 64 * 16, "64 packed gradient rows reuse the pair slots");
+  constexpr int PP = 12;  // pitch of a packed gradient row in LDS (floats): A = 6 + D <= 10
+  static_assert(A <= PP && NG * LCAP * NS >= 64 * PP, "64 packed gradient rows reuse the pair slots");
   static_assert(GSL_QB <= 127 && GSL_QB >= 64, "slots are bytes; a chunk appends up to 64 entries");
   const int grp = lane / GL, p = lane & (GL - 1);
   const float tcx = tx0 + 8.f, tcy = ty0 + 8.f;
@@ -495,7 +499,7 @@ __device__ __forceinline__ void qraster_bwd_body(
       float* packed = sb.pair;
       if (nz) {
 #pragma unroll
-        for (int k = 0; k < A; ++k) packed[lane * 16 + k] = row[k];
+        for (int k = 0; k < A; ++k) packed[lane * PP + k] = row[k];
       }
       unsigned long long mask = __ballot(nz);
       int cntz = __popcll(mask);
@@ -509,7 +513,7 @@ __device__ __forceinline__ void qraster_bwd_body(
           // (byte offset in 32 bits -- Gaussian ids are below 2^26, include/gsloc_hip.h -- so the atomic takes the scalar
           // base + a 32-bit lane offset instead of three instructions of 64-bit address arithmetic)
           const unsigned off = ((unsigned)sb.id[sl + 64 * u] << 6) | ((unsigned)f << 2);
-          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(vacc) + off), packed[sl * 16 + f]);
+          atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(vacc) + off), packed[sl * PP + f]);
         }
       }
       __syncthreads();
