@@ -325,9 +325,10 @@ __device__ __forceinline__ void qraster_bwd_body(
     (void)cnt_tot;
     for (int k = cnt_my + p; k < kmax + 3; k += GL) mylist[k] = (uint8_t)GSL_QB;  // sentinel padding (+3: read-ahead)
     __syncthreads();
-    float mo[2][NV];
+    constexpr int NU = (GSL_QB + 63) / 64;  // staged slots per lane (1 since a batch holds 64 entries)
+    float mo[NU][NV];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int q = 0; q < NV; ++q) mo[u][q] = 0.f;
     // One trip: the gradient sums of list entry (slot t, records c0 / c1) over this lane's pixel group, r (and r2)
@@ -430,7 +431,7 @@ __device__ __forceinline__ void qraster_bwd_body(
       __syncthreads();
       // gather: lane L adds up the pairs of slots L and L + 64 that lie in this round, in group order
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         int slot = lane + 64 * u;
         if (slot < staged) {
 #pragma unroll
@@ -460,7 +461,7 @@ __device__ __forceinline__ void qraster_bwd_body(
     }
     // ---- moments -> gradient rows, 64 slots at a time (the packed rows reuse the pair slots)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
       int slot = lane + 64 * u;
       bool nz = false;
       float row[A];
