@@ -30,6 +30,8 @@ TINY_RCULL_MAX = 1.999  # r_cull below this: the alpha >= 1/255 disc spans at mo
 # Above this many Gaussians the general backward is the faster one even on a depth frame (end of round 4, whole tracker
 # iterations per second, tiny / general: 102 k 12 930 / 12 360, 307 k 7 020 / 7 090, 816 k 3 390 / 3 510; the step of
 # workload D 0.283 / 0.270 ms): the slabs are 256 bytes of traffic per Gaussian, the launch they save a few microseconds.
+# Render modes with colour only: with one composited channel ("ED", what gsplatloc_amd.eval renders) the slabs still win
+# at 816 k (3 990 against 3 710 it/s).
 TINY_MAX_N = 400_000
 
 
@@ -319,12 +321,12 @@ class RenderContext:
     def _choose_backward(self) -> None:
         """Tiny-splat backward (per-splat 4x4 record slabs, no reduction, no atomics) when no splat reaches
         more than 4x4 pixel centres (r_cull < 2 px) -- GsplatLoc's as-coded scales; otherwise the general
-        compositing backward.  Only for at most TINY_MAX_N Gaussians in a screen-coherent order
+        compositing backward.  Only for at most TINY_MAX_N Gaussians (any number in a one-channel mode) in a screen-coherent order
         (_screen_coherent_order)."""
         r_max = float(self.Q1[:, 3].max()) if self.N else 0.0
         mode = os.environ.get("GSLOC_BWD", "auto")  # dev switch: "general" / "tiny" (whatever the order) / "auto"
         want = (mode != "general" and r_max < TINY_RCULL_MAX and self.Qh is None and getattr(self, "allow_tiny", True)
-                and (mode == "tiny" or (self.N <= TINY_MAX_N and self._screen_coherent_order())))
+                and (mode == "tiny" or ((self.N <= TINY_MAX_N or self.D == 1) and self._screen_coherent_order())))
         if want and self.trec is None:
             self.trec = torch.zeros(self.N, 32, dtype=torch.float32, device=self.device)
             self.vcT = torch.zeros(self.H, self.W, self.D, dtype=torch.float32, device=self.device)
