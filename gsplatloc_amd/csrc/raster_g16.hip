@@ -183,7 +183,7 @@ struct QStage {
   float4 s1[GSL_QBS];  // .w = the entry's absolute list index (bits), not r_cull: the walk tests it against last_ids
   float4 s2[(D >= 3 && CG == D) ? GSL_QBS : 1];
   int32_t id[GSL_QBS];
-  // per slot, word w: position in the lists of groups 4w .. 4w+3 (7 bits each) | those groups' hit bits << 28
+  // per slot, word w: position in the lists of groups 4w .. 4w+3 (7 bits each; 127 = not in that list)
   uint32_t posn[G16_NG / 4][GSL_QBS];
   alignas(16) float pair[G16_NG * LCAP * NS];  // [group][trip of the round][value]; reused for 64 packed gradient rows
   uint8_t rlist[G16_NG][GSL_QBS + 4];          // per group: slots in walk order, padded with the sentinel slot
@@ -205,7 +205,7 @@ __device__ __forceinline__ void qraster_bwd_body(
   constexpr int NG = G16_NG, GL = G16_GL;
   constexpr int PP = 12;  // pitch of a packed gradient row in LDS (floats): A = 6 + D <= 10
   static_assert(A <= PP && NG * LCAP * NS >= 64 * PP, "64 packed gradient rows reuse the pair slots");
-  static_assert(GSL_QB <= 127 && GSL_QB >= 64, "slots are bytes; a chunk appends up to 64 entries");
+  static_assert(GSL_QB < 127 && GSL_QB >= 64, "7-bit list positions with 127 reserved; a chunk appends up to 64 entries");
   const int grp = lane / GL, p = lane & (GL - 1);
   const float tcx = tx0 + 8.f, tcy = ty0 + 8.f;
   const float lx = px - tcx, ly = py - tcy;
@@ -284,16 +284,18 @@ __device__ __forceinline__ void qraster_bwd_body(
       }
       unsigned long long R = __ballot(nib != 0);
       int slot = staged + __popcll(R & lt);
+      // positions of this entry in the group lists, 7 bits each; 127 = "not in that list" (no round ever reaches it: a
+      // list holds at most GSL_QB entries), so the gather needs no hit bit next to the position
       unsigned pack[NG / 4];
 #pragma unroll
-      for (int w = 0; w < NG / 4; ++w) pack[w] = ((nib >> (4 * w)) & 15u) << 28;
+      for (int w = 0; w < NG / 4; ++w) pack[w] = 0x0FFFFFFFu;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         unsigned long long Bg = __ballot(nib & (1u << g));
         if (__builtin_amdgcn_inverse_ballot_w64(Bg)) {  // (exec = the ballot: not a second compare of the same bit)
           int q = cnt[g] + __popcll(Bg & lt);
           sb.rlist[g][q] = (uint8_t)slot;
-          pack[g >> 2] |= (unsigned)q << (7 * (g & 3));
+          pack[g >> 2] ^= (127u ^ (unsigned)q) << (7 * (g & 3));
         }
         cnt[g] += __popcll(Bg);
       }
@@ -440,8 +442,8 @@ __device__ __forceinline__ void qraster_bwd_body(
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
               const int g = 4 * w + g4;
-              int q = (int)((pk >> (7 * g4)) & 127u) - k0;
-              if (((pk >> (28 + g4)) & 1u) && q >= 0 && q < LCAP) {
+              const unsigned q = ((pk >> (7 * g4)) & 127u) - (unsigned)k0;
+              if (q < (unsigned)LCAP) {
                 const float4* src = reinterpret_cast<const float4*>(&sb.pair[(g * LCAP + q) * NS]);
                 float4 a = src[0], c = src[1];
                 mo[u][0] += a.x; mo[u][1] += a.y; mo[u][2] += a.z; mo[u][3] += a.w;
@@ -506,10 +508,13 @@ __device__ __forceinline__ void qraster_bwd_body(
       int cntz = __popcll(mask);
       if (nz) sb.nzlist[__popcll(mask & lt)] = (uint8_t)lane;
       __syncthreads();
-      int f = lane & 15;
-      for (int i0 = 0; i0 < cntz; i0 += 4) {
-        int gi = i0 + (lane >> 4);
-        if (gi < cntz && f < A) {
+      // A lanes per row, 64 / A rows per atomic instruction (6 rows of 10 floats in "RGB+ED", 9 of 7 in "ED"; a row's
+      // lanes stay contiguous: one 64-byte line per row)
+      constexpr int RPI = 64 / A;
+      const int arow = lane / A, f = lane - arow * A;
+      for (int i0 = 0; i0 < cntz; i0 += RPI) {
+        int gi = i0 + arow;
+        if (gi < cntz && arow < RPI) {
           int sl = sb.nzlist[gi];
           // (byte offset in 32 bits -- Gaussian ids are below 2^26, include/gsloc_hip.h -- so the atomic takes the scalar
           // base + a 32-bit lane offset instead of three instructions of 64-bit address arithmetic)
